@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: attention forward TFLOPS/GPU, bf16, seqlen=4096, hdim=128, causal
+(BASELINE.json configs[2], the Llama-3-8B shape B=16 H=32), on synthetic N(0,1) tensors.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  The batch x heads axis shards embarrassingly: every rank owns its own
+B=16 shard (weak scaling) and there is NO collective on the data path -- torch.distributed (RCCL)
+is used only for the two timing barriers and the max-over-ranks reduction of the elapsed time.
+
+A "step" = one launch of the prefill kernel over the rank's whole shard, inputs resident in HBM.
+FLOPs follow the FlashAttention convention: 4*B*H*Sq*Sk*D, halved for causal.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec
+
+WORKLOAD = dict(batch=16, heads=32, seqlen=4096, head_dim=128, causal=True)
+DECODE = dict(batch=256, heads=32, seqlen_k=8192, head_dim=128)     # BASELINE.json configs[3]
+
+
+def attn_flops(B, H, Sq, Sk, D, causal):
+    f = 4.0 * B * H * Sq * Sk * D
+    return f / 2 if causal else f
+
+
+def cpu_baseline(torch, seconds_budget=20.0):
+    """PyTorch eager SDPA on the host cores (the north_star's stated CPU baseline), fp32, same
+    seqlen/hdim/causal as the workload on a bounded sample of (batch, head) pairs."""
+    from oracle import sdpa_torch_cpu          # cpu_baseline leg: allowed to use oracle/
+    S, D = WORKLOAD["seqlen"], WORKLOAD["head_dim"]
+    H = 8
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn((1, H, S, D), generator=g) for _ in range(3))
+    sdpa_torch_cpu(q, k, v, causal=True)       # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget / 2 and len(times) < 10):
+        t0 = time.perf_counter()
+        sdpa_torch_cpu(q, k, v, causal=True)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(attn_flops(1, H, S, S, D, True) / med / 1e12, 4), "unit": "TFLOPS",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"F.scaled_dot_product_attention fp32 is_causal, B=1 H={H} S={S} D={D} "
+                      f"(1/{WORKLOAD['batch'] * WORKLOAD['heads'] // H} of the GPU step), "
+                      f"median of {len(times)} runs, {med * 1e3:.0f} ms each"}
+
+
+def bench_decode(torch, sfa, steps, warmup):
+    """BASELINE.json configs[3]: B=256 Sq=1 Sk=8192 H=32 D=128 bf16 decode, HBM-bound.
+    Algorithmic bytes = K + V rows read once + qkv + o."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, H, Sk, D = DECODE["batch"], DECODE["heads"], DECODE["seqlen_k"], DECODE["head_dim"]
+    M = Sk
+    free, _ = torch.cuda.mem_get_info()
+    need = 2 * B * M * H * D * 2
+    if free < need + (4 << 30):
+        return {"skipped": f"needs {need >> 30} GiB"}
+    kc = torch.empty((B, 1, M, H, D), dtype=torch.bfloat16, device=dev)
+    vc = torch.empty_like(kc)
+    # fill on the device, chunked (a 16 GiB normal_() temp would double the footprint)
+    for t in (kc, vc):
+        flat = t.view(-1)
+        step = 1 << 28
+        for i in range(0, flat.numel(), step):
+            flat[i:i + step].normal_()
+    qkv = torch.randn((B, 3, H, D), device=dev).bfloat16()
+    o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
+    sl = torch.full((B,), Sk - 1, dtype=torch.int32, device=dev)
+    z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
+    run = lambda: sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, D, M, 1, 0)
+    for _ in range(warmup):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    nbytes = 2.0 * B * Sk * H * D * 2 + (3 + 1) * B * H * D * 2
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    del kc, vc
+    torch.cuda.empty_cache()
+    return {"workload": "decode B=256 Sq=1 Sk=8192 H=32 D=128 bf16 (fused RoPE+append)",
+            "ms_per_step": round(ms, 4), "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+            "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4), "bound": "hbm",
+            "algorithmic_bytes": nbytes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import starflashattention_amd as sfa
+    sfa._lib.load()                      # fail loudly if the HIP library is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL; barriers + one scalar reduction only
+
+    B, H, S, D = (WORKLOAD[k] for k in ("batch", "heads", "seqlen", "head_dim"))
+    causal = WORKLOAD["causal"]
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)      # every rank: its own shard
+    q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev, dtype=torch.float32).bfloat16()
+               for _ in range(3))
+    out = torch.empty_like(q)
+
+    def step():
+        sfa.flash_attn_fwd(q, k, v, causal=causal, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()                                  # same stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps          # avg launch duration (back-to-back launches)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    flops_step = attn_flops(B, H, S, S, D, causal)        # per rank
+    total_tflops = world * flops_step * args.steps / elapsed / 1e12
+    kern_tflops = flops_step / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        rec = {
+            "metric": "attention fwd TFLOPS/GPU (% MFMA peak), bf16 seqlen=4096 hdim=128",
+            "value": round(total_tflops, 2), "unit": "TFLOPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "prefill fwd causal, B=16 H=32 S=4096 D=128 per GPU "
+                                   "(BASELINE.json configs[2]); batch-sharded, no collectives",
+                       "global_batch": B * world, "seq_len": S, "heads": H, "head_dim": D,
+                       "causal": causal, "parallelism": f"batch-shard x{world}"},
+            "tflops_per_gpu": round(total_tflops / world, 2),
+            "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal>",
+                         "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},
+        }
+        if world == 1 and not args.no_decode:
+            try:
+                del q, k, v, out
+                torch.cuda.empty_cache()
+                rec["decode_roofline"] = bench_decode(torch, sfa, max(3, args.steps // 2), 2)
+            except Exception as e:                      # the headline number must still print
+                rec["decode_roofline"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(torch)
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

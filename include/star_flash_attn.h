@@ -1,0 +1,163 @@
+/*
+ * star_flash_attn.h -- C ABI of libStarFlashAttention.so (MI355X / gfx950 build).
+ *
+ * This is the drop-in boundary for the reference's one hot path (fused decode
+ * attention) plus the prefill forward the north-star adds.  Plain pointers and
+ * sizes only: no torch / ATen types, no C++ in the signatures.  Every pointer
+ * is a DEVICE pointer unless it says "host".  `stream` is a hipStream_t passed
+ * as void* (NULL = the null stream).  All entry points are asynchronous on
+ * `stream`, allocate nothing, never synchronise the device and are safe to
+ * capture in a hipGraph.  They return SFA_OK or a negative sfa_status;
+ * sfa_last_error() gives the message for the calling thread.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   sfa_decode                  <- run_flash_decoder<T>      src/flash_attn.h:7-8,  src/flash_attn.cu:937-1018
+ *                                  (+ the two kernels it launches, cu:554-935)
+ *   sfa_decode_args             <- Flash_decoder_input       src/params.h:10-51
+ *                                  Flash_decoder_params      src/params.h:53-58
+ *                                  Flash_decoder_buffers     src/params.h:60-68 (now `workspace`)
+ *   sfa_compute_rotary_table    <- compute_rotary_table<T>   src/flash_attn.h:9-10, cu:512-538
+ *   sfa_fill_16bit              <- init_half_array           src/flash_attn.h:11,   cu:493-510
+ *   sfa_prefill_fwd             <- (no reference function; BASELINE.json configs 2,3,5)
+ * The Python-facing mha_fwd_cuda (src/flash_api.cpp:42-68) and the C++ template
+ * surface (src/flash_attn.h) in this repo are thin layers over these symbols.
+ */
+#ifndef STAR_FLASH_ATTN_C_API_H_
+#define STAR_FLASH_ATTN_C_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFA_ABI_VERSION 1
+
+typedef enum sfa_status {
+    SFA_OK = 0,
+    SFA_ERR_NULL_POINTER = -1,   /* a required pointer is NULL                       */
+    SFA_ERR_BAD_SHAPE = -2,      /* sizes/strides out of the supported range         */
+    SFA_ERR_BAD_DTYPE = -3,
+    SFA_ERR_UNSUPPORTED_HEAD_DIM = -4,
+    SFA_ERR_WORKSPACE_TOO_SMALL = -5,
+    SFA_ERR_LAUNCH = -6,         /* HIP reported a launch/runtime failure            */
+    SFA_ERR_SEQ_LEN_RANGE = -7   /* reported by sfa_decode_poll_status: some
+                                    seq_len[b] was outside [0, memory_max_len)       */
+} sfa_status;
+
+typedef enum sfa_dtype {
+    SFA_DTYPE_FP16 = 0,          /* IEEE half  (the reference's only dtype)          */
+    SFA_DTYPE_BF16 = 1
+} sfa_dtype;
+
+/* ---- library ------------------------------------------------------------------ */
+int sfa_abi_version(void);
+const char *sfa_status_string(int status);
+const char *sfa_last_error(void);            /* thread-local, never NULL            */
+
+/* ---- decode: one new token per sequence, fused RoPE + KV append + split-KV ----- */
+/*
+ * Field order, names and meaning of the first block mirror Flash_decoder_input
+ * (src/params.h:10-51) so a binding can fill it 1:1; the trailing fields replace
+ * Flash_decoder_params / Flash_decoder_buffers.
+ *
+ * Semantics, for every (b, h):
+ *   pos   = seq_len[b]                      tokens already cached, 0 <= pos < memory_max_len
+ *   q,k,v = qkv[b, {0,1,2}, h, :] (+ bias)  16-bit, `stride` elements between batches
+ *   q,k   = rope(q,k; pos)                  interleaved pairs (x[2j], x[2j+1]),
+ *                                           angle pos * 10000^(-2j/rot_dim) for 2j < rot_dim,
+ *                                           fp32 math, result rounded to the 16-bit dtype
+ *   k_cache[b, idx_layer, pos, h, :] = k;  v_cache[b, idx_layer, pos, h, :] = v
+ *   o[b, h, :] = softmax(q . K[0..pos]^T * head_dim_inv) . V[0..pos]     (fp32 accumulate)
+ * Caches are [batch, num_layer, memory_max_len, num_heads, head_dim], contiguous.
+ * seq_len is NOT incremented (caller's job, as in the reference).
+ * A sequence whose seq_len is out of range is left untouched in the caches, gets
+ * NaN in o[b] and raises the sticky status word (see sfa_decode_poll_status).
+ */
+typedef struct sfa_decode_args {
+    void *qkv;                      /* [batch, 3, num_heads, head_dim]                */
+    const void *q_bias;             /* [num_heads, head_dim] or NULL                  */
+    const void *k_bias;             /* [num_heads, head_dim] or NULL                  */
+    const void *v_bias;             /* [num_heads, head_dim] or NULL                  */
+    void *o;                        /* [batch, num_heads, head_dim]                   */
+    const void *seq_len;            /* int32 [batch]                                  */
+    void *k_cache_table;            /* see above; written at one row per sequence     */
+    void *v_cache_table;
+    const void *rotary_cos_table;   /* [memory_max_len, rot_dim/2] 16-bit, or NULL:   */
+    const void *rotary_sin_table;   /*   NULL => cos/sin computed in-kernel in fp32   */
+    int batch_size;
+    int memory_max_len;
+    int num_heads;
+    int head_dim;                   /* 64 or 128                                      */
+    float head_dim_inv;             /* softmax scale; <= 0 => 1/sqrt(head_dim)        */
+    int rotary_embedding_dim;       /* even, 0..head_dim                              */
+    int max_input_length;           /* carried for interface parity; unused           */
+    int stride;                     /* elements between qkv batches; 0 => 3*H*D       */
+    int num_layer;
+    int idx_layer;
+    /* -- replaces Flash_decoder_params (kBlockN / kNThreads are internal now) -- */
+    int num_splits;                 /* KV splits per (b,h); <= 0 => chosen by the library */
+    int dtype;                      /* sfa_dtype                                      */
+    /* -- replaces Flash_decoder_buffers -- */
+    void *workspace;                /* >= sfa_decode_workspace_bytes(...), 256-B aligned */
+    size_t workspace_bytes;
+} sfa_decode_args;
+
+/* Bytes of scratch sfa_decode needs for this shape (num_splits <= 0: the library's choice
+ * for this shape, which is what sfa_decode will then use). Never 0: the first 256 bytes hold
+ * the status word. */
+size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim,
+                                  int memory_max_len, int num_splits);
+/* The split count the library picks for num_splits <= 0. */
+int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len);
+/* Zero the sticky status word (async). Call once after allocating a workspace. */
+int sfa_decode_reset_status(void *workspace, void *stream);
+/* Synchronises `stream`, reads the status word: SFA_OK or SFA_ERR_SEQ_LEN_RANGE. */
+int sfa_decode_poll_status(const void *workspace, void *stream);
+int sfa_decode(const sfa_decode_args *args, void *stream);
+
+/* ---- prefill: O = softmax(mask(Q K^T * scale)) V ------------------------------- */
+/*
+ * q [batch, heads_q, seqlen_q, head_dim], k/v [batch, heads_kv, seqlen_k, head_dim],
+ * o like q; any batch/head/seq strides (in elements), head_dim contiguous, 16-byte
+ * aligned rows.  heads_q % heads_kv == 0 (GQA: query head h reads kv head
+ * h / (heads_q/heads_kv)).  causal != 0: key j visible to query i iff
+ * j <= i + (seqlen_k - seqlen_q).  lse (optional, fp32 [batch, heads_q, seqlen_q],
+ * contiguous) receives log(sum(exp(scaled scores))) per row.  A row with no visible
+ * key gets zeros (lse = -inf).
+ */
+typedef struct sfa_prefill_args {
+    const void *q;
+    const void *k;
+    const void *v;
+    void *o;
+    float *lse;                     /* may be NULL                                    */
+    int batch;
+    int heads_q;
+    int heads_kv;
+    int seqlen_q;
+    int seqlen_k;
+    int head_dim;                   /* 64 or 128                                      */
+    int64_t q_stride[3];            /* {batch, head, seq} strides in elements         */
+    int64_t k_stride[3];
+    int64_t v_stride[3];
+    int64_t o_stride[3];
+    float softmax_scale;            /* <= 0 => 1/sqrt(head_dim)                       */
+    int causal;
+    int dtype;                      /* sfa_dtype                                      */
+} sfa_prefill_args;
+
+int sfa_prefill_fwd(const sfa_prefill_args *args, void *stream);
+
+/* ---- small helpers the reference's C++ harness uses ----------------------------- */
+/* cos/sin LUT, [max_seq_len, rot_dim/2] each, entry (pos, j) = cos/sin(pos * 10000^(-2j/rot_dim)). */
+int sfa_compute_rotary_table(void *cos_table, void *sin_table, int max_seq_len,
+                             int rot_dim, int dtype, void *stream);
+/* array[i] = bits for i < n (16-bit elements). */
+int sfa_fill_16bit(void *array, uint16_t bits, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAR_FLASH_ATTN_C_API_H_ */

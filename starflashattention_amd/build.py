@@ -1,0 +1,134 @@
+"""Build the native pieces in-tree with hipcc for gfx950 (no cmake, no JIT cache).
+
+  libStarFlashAttention.so   HIP kernels + C ABI (include/star_flash_attn.h) + the C++ template
+                             surface of src/flash_attn.h           -> starflashattention_amd/lib/
+  star_flash_attn*.so        pybind11/ATen binding (src/flash_api.cpp), same module name and
+                             function as the reference's extension  -> repo root
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the built .so
+files travel to the GPU box with the tree (they are git-ignored, not gpurun-ignored).
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "starflashattention_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "starflashattention_amd", "lib")
+OBJDIR = os.path.join(ROOT, "build", "obj")
+LIB_NAME = "libStarFlashAttention.so"
+ARCH = "gfx950"
+
+KERNEL_SOURCES = ["decode_kernel.hip", "prefill_kernel.hip", "aux_kernels.hip", "c_api.hip",
+                  "cxx_surface.hip"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm >= 7.0 with gfx950 support)")
+    return exe
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _stamp(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(p.encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(ROOT, "include", "star_flash_attn.h")]
+    hs += [os.path.join(ROOT, "src", f) for f in ("params.h", "traits.h", "flash_attn.h")]
+    return [h for h in hs if os.path.exists(h)]
+
+
+def build_lib(force=False, verbose=False, extra_flags=()):
+    """hipcc -> starflashattention_amd/lib/libStarFlashAttention.so; returns its path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, LIB_NAME)
+    srcs = [os.path.join(CSRC, s) for s in KERNEL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + ROOT,
+             "-Wall", "-Wno-unused-function"] + list(extra_flags)
+    stamp = _stamp(srcs + _headers(), " ".join(flags))
+    stamp_file = out + ".stamp"
+    if (not force and os.path.exists(out) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
+        return out
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        log = _run([cc] + flags + ["-c", src, "-o", obj])
+        if verbose and log.strip():
+            print(log)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return out
+
+
+def build_pybind(force=False, verbose=False):
+    """Compile src/flash_api.cpp into the top-level `star_flash_attn` extension module."""
+    import torch
+    from torch.utils import cpp_extension
+
+    lib = build_lib()
+    src = os.path.join(ROOT, "src", "flash_api.cpp")
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    out = os.path.join(ROOT, "star_flash_attn" + suffix)
+    stamp = _stamp([src] + _headers(), torch.__version__)
+    stamp_file = os.path.join(ROOT, "build", "star_flash_attn.stamp")
+    if (not force and os.path.exists(out) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
+        return out
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    inc = cpp_extension.include_paths(device_type="cuda")     # torch-ROCm: adds the HIP include dirs
+    tlib = cpp_extension.library_paths(device_type="cuda")
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=star_flash_attn",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-Wno-deprecated-declarations", "-I" + ROOT, "-I" + sysconfig.get_paths()["include"]]
+    cmd += ["-I" + i for i in inc]
+    cmd += [src, "-o", out]
+    cmd += ["-L" + p for p in tlib] + ["-L" + LIBDIR]
+    cmd += ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+            "-lStarFlashAttention", "-Wl,-rpath,$ORIGIN/starflashattention_amd/lib"]
+    cmd += ["-Wl,-rpath," + p for p in tlib]
+    log = _run(cmd)
+    if verbose and log.strip():
+        print(log)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    return build_lib(force, verbose), build_pybind(force, verbose)
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    only_lib = "--lib-only" in sys.argv
+    print(build_lib(force, verbose=True))
+    if not only_lib:
+        print(build_pybind(force, verbose=True))

@@ -1,0 +1,256 @@
+// extern "C" entry points of libStarFlashAttention.so (declared in include/star_flash_attn.h).
+// Validation + parameter marshalling only; the kernels live in decode_kernel.hip,
+// prefill_kernel.hip and aux_kernels.hip.  Nothing here allocates, copies or synchronises
+// (except sfa_decode_poll_status, which exists to do exactly that).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "sfa_host.h"
+
+namespace sfa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int status, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SFA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SFA_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Split count when the caller does not choose one (the reference hard-codes 4 with a TODO,
+// flash_api.cpp:38, flash_attn.cu:1024).  Each workgroup is 4 waves on one (b,h,split); aim
+// for >= 4 workgroups per CU (1024 on 256 CUs) but keep >= 256 cached rows per workgroup so
+// every wave still streams >= 64 rows.
+static int auto_splits(int B, int H, int /*D*/, int M) {
+    const long long bh = (long long)B * H;
+    long long s = (1024 + bh - 1) / bh;
+    const long long cap = M / 256 > 1 ? M / 256 : 1;
+    if (s > cap) s = cap;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace sfa
+
+using namespace sfa;
+
+extern "C" {
+
+int sfa_abi_version(void) { return SFA_ABI_VERSION; }
+
+const char *sfa_status_string(int status) {
+    switch (status) {
+        case SFA_OK: return "ok";
+        case SFA_ERR_NULL_POINTER: return "null pointer";
+        case SFA_ERR_BAD_SHAPE: return "bad shape";
+        case SFA_ERR_BAD_DTYPE: return "bad dtype";
+        case SFA_ERR_UNSUPPORTED_HEAD_DIM: return "unsupported head_dim";
+        case SFA_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+        case SFA_ERR_LAUNCH: return "HIP launch failure";
+        case SFA_ERR_SEQ_LEN_RANGE: return "seq_len out of range";
+        default: return "unknown status";
+    }
+}
+
+const char *sfa_last_error(void) { return g_err; }
+
+int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len) {
+    if (batch_size <= 0 || num_heads <= 0 || memory_max_len <= 0) return 1;
+    return auto_splits(batch_size, num_heads, head_dim, memory_max_len);
+}
+
+size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim, int memory_max_len,
+                                  int num_splits) {
+    if (batch_size <= 0 || num_heads <= 0 || head_dim <= 0) return kStatusBytes;
+    const int S = num_splits > 0 ? num_splits : auto_splits(batch_size, num_heads, head_dim, memory_max_len);
+    size_t bytes = kStatusBytes;
+    if (S > 1) {
+        const size_t bhs = (size_t)batch_size * num_heads * S;
+        bytes += align_up(bhs * head_dim * sizeof(float), 256);
+        bytes += align_up(bhs * sizeof(float2), 256);
+    }
+    return bytes;
+}
+
+int sfa_decode_reset_status(void *workspace, void *stream) {
+    if (!workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode_reset_status: workspace is NULL");
+    const hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(SFA_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return SFA_OK;
+}
+
+int sfa_decode_poll_status(const void *workspace, void *stream) {
+    if (!workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode_poll_status: workspace is NULL");
+    int32_t word = 0;
+    hipError_t e = hipMemcpyAsync(&word, workspace, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(SFA_ERR_LAUNCH, "sfa_decode_poll_status: %s", hipGetErrorString(e));
+    if (word != 0)
+        return fail(SFA_ERR_SEQ_LEN_RANGE,
+                    "sfa_decode: some seq_len[b] was outside [0, memory_max_len); those outputs are NaN "
+                    "and their cache rows were not written");
+    return SFA_OK;
+}
+
+int sfa_decode(const sfa_decode_args *a, void *stream) {
+    if (!a) return fail(SFA_ERR_NULL_POINTER, "sfa_decode: args is NULL");
+    if (!a->qkv || !a->o || !a->seq_len || !a->k_cache_table || !a->v_cache_table)
+        return fail(SFA_ERR_NULL_POINTER, "sfa_decode: qkv/o/seq_len/k_cache_table/v_cache_table must be non-NULL");
+    if ((a->rotary_cos_table == nullptr) != (a->rotary_sin_table == nullptr))
+        return fail(SFA_ERR_NULL_POINTER, "sfa_decode: give both rotary tables or neither");
+    if (a->batch_size < 0 || a->num_heads <= 0 || a->memory_max_len <= 0 || a->num_layer <= 0)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: batch_size=%d num_heads=%d memory_max_len=%d num_layer=%d",
+                    a->batch_size, a->num_heads, a->memory_max_len, a->num_layer);
+    if (a->idx_layer < 0 || a->idx_layer >= a->num_layer)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: idx_layer=%d outside [0, num_layer=%d)", a->idx_layer, a->num_layer);
+    if (a->head_dim != 64 && a->head_dim != 128)
+        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128}", a->head_dim);
+    if (a->rotary_embedding_dim < 0 || a->rotary_embedding_dim > a->head_dim || (a->rotary_embedding_dim & 1))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: rotary_embedding_dim=%d must be even and in [0, head_dim]",
+                    a->rotary_embedding_dim);
+    if (a->dtype != SFA_DTYPE_FP16 && a->dtype != SFA_DTYPE_BF16)
+        return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", a->dtype);
+    const long long hd = (long long)a->num_heads * a->head_dim;
+    const long long stride = a->stride > 0 ? a->stride : 3 * hd;
+    if (stride < 3 * hd || (stride % 8) != 0)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= 3*H*D and a multiple of 8", stride);
+    if (a->num_splits > 1024)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_splits=%d > 1024", a->num_splits);
+    const uintptr_t align_or = (uintptr_t)a->qkv | (uintptr_t)a->o | (uintptr_t)a->k_cache_table |
+                               (uintptr_t)a->v_cache_table | (uintptr_t)a->q_bias | (uintptr_t)a->k_bias |
+                               (uintptr_t)a->v_bias;
+    if (align_or & 15) return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: tensors must be 16-byte aligned");
+    if (a->batch_size == 0) return SFA_OK;
+
+    const int S = a->num_splits > 0
+                      ? a->num_splits
+                      : auto_splits(a->batch_size, a->num_heads, a->head_dim, a->memory_max_len);
+    const size_t need = sfa_decode_workspace_bytes(a->batch_size, a->num_heads, a->head_dim,
+                                                   a->memory_max_len, S);
+    if (!a->workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode: workspace is NULL (need %zu bytes)", need);
+    if (a->workspace_bytes < need)
+        return fail(SFA_ERR_WORKSPACE_TOO_SMALL, "sfa_decode: workspace has %zu bytes, need %zu",
+                    a->workspace_bytes, need);
+    if ((uintptr_t)a->workspace & 255)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: workspace must be 256-byte aligned");
+
+    DecodeKernelParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = (const uint16_t *)a->qkv;
+    p.q_bias = (const uint16_t *)a->q_bias;
+    p.k_bias = (const uint16_t *)a->k_bias;
+    p.v_bias = (const uint16_t *)a->v_bias;
+    p.o = (uint16_t *)a->o;
+    p.seq_len = (const int32_t *)a->seq_len;
+    p.k_cache = (uint16_t *)a->k_cache_table;
+    p.v_cache = (uint16_t *)a->v_cache_table;
+    p.cos_tab = (const uint16_t *)a->rotary_cos_table;
+    p.sin_tab = (const uint16_t *)a->rotary_sin_table;
+    char *ws = (char *)a->workspace;
+    p.status = (int32_t *)ws;
+    const size_t bhs = (size_t)a->batch_size * a->num_heads * S;
+    p.part_o = (float *)(ws + kStatusBytes);
+    p.part_ml = (float2 *)(ws + kStatusBytes + align_up(bhs * a->head_dim * sizeof(float), 256));
+    p.B = a->batch_size;
+    p.M = a->memory_max_len;
+    p.H = a->num_heads;
+    p.L = a->num_layer;
+    p.layer = a->idx_layer;
+    p.rot_dim = a->rotary_embedding_dim;
+    p.num_splits = S;
+    p.qkv_stride = stride;
+    const float scale = a->head_dim_inv > 0.f ? a->head_dim_inv : 1.0f / std::sqrt((float)a->head_dim);
+    p.scale_log2 = scale * 1.4426950408889634f;
+    return launch_decode(p, a->dtype, a->head_dim, (hipStream_t)stream);
+}
+
+int sfa_prefill_fwd(const sfa_prefill_args *a, void *stream) {
+    if (!a) return fail(SFA_ERR_NULL_POINTER, "sfa_prefill_fwd: args is NULL");
+    if (!a->q || !a->k || !a->v || !a->o)
+        return fail(SFA_ERR_NULL_POINTER, "sfa_prefill_fwd: q/k/v/o must be non-NULL");
+    if (a->batch < 0 || a->heads_q <= 0 || a->heads_kv <= 0 || a->seqlen_q < 0 || a->seqlen_k < 0)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: batch=%d heads_q=%d heads_kv=%d seqlen_q=%d seqlen_k=%d",
+                    a->batch, a->heads_q, a->heads_kv, a->seqlen_q, a->seqlen_k);
+    if (a->heads_q % a->heads_kv)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: heads_q=%d not a multiple of heads_kv=%d", a->heads_q, a->heads_kv);
+    if (a->head_dim != 64 && a->head_dim != 128)
+        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: head_dim %d not in {64, 128}", a->head_dim);
+    if (a->dtype != SFA_DTYPE_FP16 && a->dtype != SFA_DTYPE_BF16)
+        return fail(SFA_ERR_BAD_DTYPE, "sfa_prefill_fwd: dtype %d is not fp16(0)/bf16(1)", a->dtype);
+    const int64_t *st[4] = {a->q_stride, a->k_stride, a->v_stride, a->o_stride};
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 3; ++i)
+            if (st[t][i] < 0 || (st[t][i] % 8) != 0)
+                return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: strides must be >= 0 and multiples of 8 elements");
+    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: tensors must be 16-byte aligned");
+    if ((long long)a->batch * a->heads_q > (1ll << 24))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: batch*heads_q too large");
+    if (a->batch == 0 || a->seqlen_q == 0) return SFA_OK;
+    if (a->seqlen_k == 0) {
+        // no keys: every row is empty -> zeros (the kernel handles nt == 0, but it clamps key
+        // rows to Sk-1 when staging, so give it nothing to read)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: seqlen_k must be > 0");
+    }
+
+    PrefillKernelParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const uint16_t *)a->q;
+    p.k = (const uint16_t *)a->k;
+    p.v = (const uint16_t *)a->v;
+    p.o = (uint16_t *)a->o;
+    p.lse = a->lse;
+    p.B = a->batch;
+    p.Hq = a->heads_q;
+    p.Hkv = a->heads_kv;
+    p.Sq = a->seqlen_q;
+    p.Sk = a->seqlen_k;
+    for (int i = 0; i < 3; ++i) {
+        p.qs[i] = a->q_stride[i];
+        p.ks[i] = a->k_stride[i];
+        p.vs[i] = a->v_stride[i];
+        p.os[i] = a->o_stride[i];
+    }
+    const float scale = a->softmax_scale > 0.f ? a->softmax_scale : 1.0f / std::sqrt((float)a->head_dim);
+    p.scale_log2 = scale * 1.4426950408889634f;
+    p.nq_tiles = (a->seqlen_q + 255) / 256;
+    p.bh_per_xcd = (a->batch * a->heads_q + 7) / 8;
+    if ((long long)8 * p.bh_per_xcd * p.nq_tiles > 0x7fffffffll)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: grid too large");
+    return launch_prefill(p, a->dtype, a->head_dim, a->causal != 0, (hipStream_t)stream);
+}
+
+int sfa_compute_rotary_table(void *cos_table, void *sin_table, int max_seq_len, int rot_dim, int dtype,
+                             void *stream) {
+    if (!cos_table || !sin_table) return fail(SFA_ERR_NULL_POINTER, "sfa_compute_rotary_table: NULL table");
+    if (max_seq_len < 0 || rot_dim < 0 || (rot_dim & 1))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_compute_rotary_table: max_seq_len=%d rot_dim=%d", max_seq_len, rot_dim);
+    return launch_rotary_table(cos_table, sin_table, max_seq_len, rot_dim, dtype, (hipStream_t)stream);
+}
+
+int sfa_fill_16bit(void *array, uint16_t bits, size_t n, void *stream) {
+    if (!array && n) return fail(SFA_ERR_NULL_POINTER, "sfa_fill_16bit: NULL array");
+    return launch_fill16(array, bits, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// Single-token decode attention for gfx950 (MI355X): fused QKV unpack + bias + interleaved
+// RoPE + KV-cache append + split-KV online softmax, and the split combine.
+//
+// Replaces (semantics, not code) the reference's flash_decoder_kernel / flash_combine_kernel
+// and their device helpers (src/flash_attn.cu:554-875, 877-935, 161-447) -- see SURVEY.md
+// section 8(a) rows A3-A9 for what the CUDA version intends and where it goes wrong.
+//
+// MI355X design (HBM-bound: AI = 1 FLOP/B, so the only goal is to keep HBM busy):
+//   * cache layout is the API's [B, L, M, H, D]; one (b,h) reads 2*D-byte segments at a
+//     stride of H*D*2 bytes.  D/8 lanes x 16 B cover one cache row, so one wave64
+//     global_load_dwordx4 fetches 64/(D/8) whole rows (4 rows for D=128): every 128-B line
+//     that is fetched is fully used, and neighbouring heads (blockIdx.x fastest) touch the
+//     same DRAM pages at about the same time.
+//   * K/V go straight to VGPRs (no LDS round trip: nothing is reused), U row-groups per
+//     step, register double-buffered so 2*U K-loads + 2*U V-loads (16 B/lane each) are in
+//     flight per wave; 4 waves/workgroup split the workgroup's key range.
+//   * q.k uses v_dot2c_f32_{f16,bf16}; the 16-lane (8 for D=64) row sum is 4 (3) DPP adds.
+//     Each of the 64/(D/8) lane groups runs its OWN online softmax over the rows it sees,
+//     so nothing crosses lane groups inside the loop; groups merge once per wave
+//     (__shfl_xor), waves merge once per workgroup through 2 KB of LDS.
+//   * 64-bit addressing throughout (K alone is 8.6 G elements at B=256, M=8192, H=32).
+//   * The new token never round-trips through memory: the last split's wave 0 takes
+//     k_rot / v_new from registers, adds them to its softmax stream and writes the cache row.
+#include "sfa_device.h"
+#include "sfa_host.h"
+
+namespace sfa {
+
+namespace {
+
+constexpr int kDecodeWaves = 4;
+
+__device__ __forceinline__ float neg_inf() { return -__builtin_huge_valf(); }
+
+template <class Tr>
+__device__ __forceinline__ float dot8(const uint4 &a, const uint4 &b) {
+    float s = Tr::dot2(a.x, b.x, 0.0f);
+    s = Tr::dot2(a.y, b.y, s);
+    s = Tr::dot2(a.z, b.z, s);
+    s = Tr::dot2(a.w, b.w, s);
+    return s;
+}
+
+template <class Tr>
+__device__ __forceinline__ void unpack8(const uint4 &v, float (&x)[8]) {
+    x[0] = Tr::lo_f32(v.x); x[1] = Tr::hi_f32(v.x);
+    x[2] = Tr::lo_f32(v.y); x[3] = Tr::hi_f32(v.y);
+    x[4] = Tr::lo_f32(v.z); x[5] = Tr::hi_f32(v.z);
+    x[6] = Tr::lo_f32(v.w); x[7] = Tr::hi_f32(v.w);
+}
+
+template <class Tr>
+__device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
+    return make_uint4(Tr::pack2(x[0], x[1]), Tr::pack2(x[2], x[3]),
+                      Tr::pack2(x[4], x[5]), Tr::pack2(x[6], x[7]));
+}
+
+// Running softmax state of one lane group: max (log2 units), sum, and this lane's 8 output dims.
+struct Stream {
+    float m, l, acc[8];
+    __device__ __forceinline__ void init() {
+        m = neg_inf(); l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    }
+    // fold another stream (m2, l2, acc2) into this one
+    __device__ __forceinline__ void merge(float m2, float l2, const float (&acc2)[8]) {
+        const float mn = fmaxf(m, m2);
+        const float ms = (mn == neg_inf()) ? 0.f : mn;
+        const float a1 = fast_exp2(m - ms), a2 = fast_exp2(m2 - ms);
+        l = l * a1 + l2 * a2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a1 + acc2[j] * a2;
+        m = mn;
+    }
+};
+
+template <class Tr, int D, int U>
+__global__ void __launch_bounds__(kDecodeWaves * 64)
+decode_kernel(const DecodeKernelParams p) {
+    constexpr int LPR = D / 8;          // lanes per cache row
+    constexpr int G = 64 / LPR;         // cache rows per wave-instruction
+    constexpr int STEP = G * U;         // rows per wave per step
+    const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int S = p.num_splits;
+
+    const int pos = p.seq_len[b];
+    if (pos < 0 || pos >= p.M) {
+        // out-of-range sequence: touch no cache row, poison the output, raise the sticky flag
+        if (split == 0) {
+            if (tid < D) p.o[((long long)b * p.H + h) * D + tid] = Tr::id == 0 ? 0x7e00 : 0x7fc0;
+            if (tid == 0 && h == 0) atomicOr(p.status, 1);
+        }
+        return;
+    }
+
+    // ---- q, k_new, v_new for this lane's 8 dims: bias, RoPE (fp32), round to storage ----
+    const long long qoff = (long long)b * p.qkv_stride + (long long)h * D + sub * 8;
+    const long long hd = (long long)p.H * D;
+    float xq[8], xk[8], xv[8];
+    unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.qkv + qoff), xq);
+    unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.qkv + qoff + hd), xk);
+    const uint4 v_raw = *reinterpret_cast<const uint4 *>(p.qkv + qoff + 2 * hd);
+    uint4 vpk = v_raw;
+    if (p.q_bias) {
+        float t[8]; unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.q_bias + (long long)h * D + sub * 8), t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xq[j] += t[j];
+    }
+    if (p.k_bias) {
+        float t[8]; unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.k_bias + (long long)h * D + sub * 8), t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xk[j] += t[j];
+    }
+    if (p.v_bias) {
+        float t[8]; unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.v_bias + (long long)h * D + sub * 8), t);
+        unpack8<Tr>(v_raw, xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] += t[j];
+        vpk = pack8<Tr>(xv);
+    }
+    const int rot = p.rot_dim;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pj = sub * 4 + i;                 // pair index: dims (2pj, 2pj+1)
+        if (2 * pj < rot) {
+            float c, s;
+            if (p.cos_tab) {
+                const long long ti = (long long)pos * (rot >> 1) + pj;
+                c = Tr::to_f32(p.cos_tab[ti]);
+                s = Tr::to_f32(p.sin_tab[ti]);
+            } else {
+                // same fp32 recipe as the reference oracle (testFlashDecoder.py:11,20-25)
+                const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * pj) / (float)rot);
+                const float ang = (float)pos * inv_freq;
+                sincosf(ang, &s, &c);
+            }
+            const float q0 = xq[2 * i], q1 = xq[2 * i + 1];
+            xq[2 * i] = q0 * c - q1 * s;
+            xq[2 * i + 1] = q1 * c + q0 * s;
+            const float k0 = xk[2 * i], k1 = xk[2 * i + 1];
+            xk[2 * i] = k0 * c - k1 * s;
+            xk[2 * i + 1] = k1 * c + k0 * s;
+        }
+    }
+    const uint4 qpk = pack8<Tr>(xq);
+    const uint4 kpk = pack8<Tr>(xk);
+
+    // ---- this wave's slice of the cached rows [0, pos) ----
+    const int rows_per_split = (pos + S - 1) / S;
+    const int r0 = min(pos, split * rows_per_split);
+    const int r1 = min(pos, r0 + rows_per_split);
+    int per_wave = (r1 - r0 + kDecodeWaves - 1) / kDecodeWaves;
+    per_wave = (per_wave + STEP - 1) / STEP * STEP;
+    const int w0 = min(r1, r0 + wave * per_wave);
+    const int w1 = min(r1, w0 + per_wave);
+
+    const long long head_base = (((long long)b * p.L + p.layer) * p.M * p.H + h) * (long long)D + sub * 8;
+    const uint16_t *kb = p.k_cache + head_base;
+    const uint16_t *vb = p.v_cache + head_base;
+
+    Stream st;
+    st.init();
+
+    auto load = [&](uint4 (&kk)[U], uint4 (&vv)[U], int t) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = min(t + u * G + grp, w1 - 1);       // clamp: loads stay in range
+            kk[u] = *reinterpret_cast<const uint4 *>(kb + (long long)row * hd);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = min(t + u * G + grp, w1 - 1);
+            vv[u] = *reinterpret_cast<const uint4 *>(vb + (long long)row * hd);
+        }
+    };
+    auto consume = [&](const uint4 (&kk)[U], const uint4 (&vv)[U], int t) {
+        float s[U];
+        float mx = st.m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float d = group_sum<LPR>(dot8<Tr>(kk[u], qpk));
+            s[u] = (t + u * G + grp < w1) ? d * p.scale_log2 : neg_inf();
+            mx = fmaxf(mx, s[u]);
+        }
+        const float ms = (mx == neg_inf()) ? 0.f : mx;
+        const float alpha = fast_exp2(st.m - ms);
+        st.l *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st.acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pu = fast_exp2(s[u] - ms);
+            st.l += pu;
+            float x[8];
+            unpack8<Tr>(vv[u], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st.acc[j] = fmaf(pu, x[j], st.acc[j]);
+        }
+        st.m = mx;
+    };
+
+    if (w0 < w1) {
+        uint4 ka[U], va[U], kb2[U], vb2[U];
+        load(ka, va, w0);
+        for (int t = w0; t < w1; t += 2 * STEP) {
+            const bool more1 = t + STEP < w1;
+            if (more1) load(kb2, vb2, t + STEP);
+            consume(ka, va, t);
+            if (more1) {
+                if (t + 2 * STEP < w1) load(ka, va, t + 2 * STEP);
+                consume(kb2, vb2, t + STEP);
+            }
+        }
+    }
+
+    // ---- the new token (position `pos`): registers only; last split, wave 0, lane group 0 ----
+    if (split == S - 1 && wave == 0) {
+        const float d = group_sum<LPR>(dot8<Tr>(kpk, qpk));
+        if (grp == 0) {
+            float x[8];
+            unpack8<Tr>(vpk, x);
+            const float sn = d * p.scale_log2;
+            float accn[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) accn[j] = x[j];
+            st.merge(sn, 1.0f, accn);
+            // append to the caches: LPR lanes x 16 B = one row each
+            const long long roff = (long long)pos * hd;
+            *reinterpret_cast<uint4 *>(p.k_cache + head_base + roff) = kpk;
+            *reinterpret_cast<uint4 *>(p.v_cache + head_base + roff) = vpk;
+        }
+    }
+
+    // ---- merge lane groups (same dims, different rows) ----
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
+        float a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a2[j] = __shfl_xor(st.acc[j], off);
+        st.merge(m2, l2, a2);
+    }
+
+    // ---- merge the workgroup's waves through LDS ----
+    __shared__ float red[kDecodeWaves][D + 2];
+    if (grp == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][sub * 8 + j] = st.acc[j];
+        if (sub == 0) { red[wave][D] = st.m; red[wave][D + 1] = st.l; }
+    }
+    __syncthreads();
+    if (tid < LPR) {
+        Stream tot;
+        tot.init();
+#pragma unroll
+        for (int w = 0; w < kDecodeWaves; ++w) {
+            float a2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2[j] = red[w][tid * 8 + j];
+            tot.merge(red[w][D], red[w][D + 1], a2);
+        }
+        const long long bh = (long long)b * p.H + h;
+        if (S == 1) {
+            const float inv = 1.0f / tot.l;          // l >= 1: the new token is always present
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = tot.acc[j] * inv;
+            *reinterpret_cast<uint4 *>(p.o + bh * D + tid * 8) = pack8<Tr>(y);
+        } else {
+            float *po = p.part_o + (bh * S + split) * D + tid * 8;
+            *reinterpret_cast<float4 *>(po) = make_float4(tot.acc[0], tot.acc[1], tot.acc[2], tot.acc[3]);
+            *reinterpret_cast<float4 *>(po + 4) = make_float4(tot.acc[4], tot.acc[5], tot.acc[6], tot.acc[7]);
+            if (tid == 0) p.part_ml[bh * S + split] = make_float2(tot.m, tot.l);
+        }
+    }
+}
+
+// o[b,h,:] = sum_s 2^(m_s - M) o_s / sum_s 2^(m_s - M) l_s     (fp32; reference cu:877-935 does
+// this in half precision with a -256 sentinel)
+template <class Tr, int D>
+__global__ void __launch_bounds__(256)
+decode_combine_kernel(const DecodeKernelParams p) {
+    constexpr int LPR = D / 8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long bh = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (bh >= (long long)p.B * p.H) return;
+    const int b = (int)(bh / p.H);
+    const int pos = p.seq_len[b];
+    if (pos < 0 || pos >= p.M) return;         // decode_kernel already poisoned o[b]
+    const int S = p.num_splits;
+    Stream tot;
+    tot.init();
+    for (int s = 0; s < S; ++s) {
+        const float2 ml = p.part_ml[bh * S + s];
+        const float *po = p.part_o + (bh * S + s) * D + sub * 8;
+        const float4 a = *reinterpret_cast<const float4 *>(po);
+        const float4 c = *reinterpret_cast<const float4 *>(po + 4);
+        const float a2[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        tot.merge(ml.x, ml.y, a2);
+    }
+    const float inv = 1.0f / tot.l;
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = tot.acc[j] * inv;
+    *reinterpret_cast<uint4 *>(p.o + bh * D + sub * 8) = pack8<Tr>(y);
+}
+
+template <class Tr, int D>
+int launch_decode_t(const DecodeKernelParams &p, hipStream_t stream) {
+    constexpr int U = 4;
+    dim3 grid(p.H, p.num_splits, p.B), block(kDecodeWaves * 64);
+    hipLaunchKernelGGL((decode_kernel<Tr, D, U>), grid, block, 0, stream, p);
+    int rc = check_launch("decode_kernel");
+    if (rc != SFA_OK) return rc;
+    if (p.num_splits > 1) {
+        const long long threads = (long long)p.B * p.H * (D / 8);
+        dim3 g2((unsigned)((threads + 255) / 256)), b2(256);
+        hipLaunchKernelGGL((decode_combine_kernel<Tr, D>), g2, b2, 0, stream, p);
+        rc = check_launch("decode_combine_kernel");
+    }
+    return rc;
+}
+
+}  // namespace
+
+int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
+    if (dtype == SFA_DTYPE_FP16) {
+        if (head_dim == 128) return launch_decode_t<Fp16, 128>(p, stream);
+        if (head_dim == 64) return launch_decode_t<Fp16, 64>(p, stream);
+    } else if (dtype == SFA_DTYPE_BF16) {
+        if (head_dim == 128) return launch_decode_t<Bf16, 128>(p, stream);
+        if (head_dim == 64) return launch_decode_t<Bf16, 64>(p, stream);
+    } else {
+        return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", dtype);
+    }
+    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128}", head_dim);
+}
+
+}  // namespace sfa

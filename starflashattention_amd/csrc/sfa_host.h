@@ -1,0 +1,52 @@
+// Host-side glue between the C ABI (include/star_flash_attn.h) and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/star_flash_attn.h"
+
+namespace sfa {
+
+// thread-local error text for sfa_last_error()
+void set_error(const char *fmt, ...);
+int fail(int status, const char *fmt, ...);
+
+// Workspace layout of sfa_decode: [0,256) status block, then fp32 partial outputs
+// [B,H,S,D], then float2 (m, l) [B,H,S].
+constexpr size_t kStatusBytes = 256;
+
+struct DecodeKernelParams {
+    const uint16_t *qkv;
+    const uint16_t *q_bias, *k_bias, *v_bias;
+    uint16_t *o;
+    const int32_t *seq_len;
+    uint16_t *k_cache, *v_cache;
+    const uint16_t *cos_tab, *sin_tab;
+    float *part_o;          // [B,H,S,D]   un-normalised partial outputs
+    float2 *part_ml;        // [B,H,S]     (running max in log2 units, running sum)
+    int32_t *status;        // sticky error word
+    int B, M, H, L, layer, rot_dim, num_splits;
+    long long qkv_stride;   // elements between batches of qkv
+    float scale_log2;       // softmax scale * log2(e)
+};
+
+struct PrefillKernelParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    float *lse;
+    int B, Hq, Hkv, Sq, Sk;
+    long long qs[3], ks[3], vs[3], os[3];   // {batch, head, seq} strides (elements)
+    float scale_log2;
+    int nq_tiles;           // ceil(Sq / 256)
+    int bh_per_xcd;         // ceil(B*Hq / 8)
+};
+
+int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
+int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_rotary_table(void *cos_t, void *sin_t, int max_seq_len, int rot_dim, int dtype, hipStream_t stream);
+int launch_fill16(void *arr, uint16_t bits, size_t n, hipStream_t stream);
+
+int check_launch(const char *what);
+
+}  // namespace sfa

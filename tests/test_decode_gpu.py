@@ -1,0 +1,253 @@
+"""GPU parity of the HIP decode path (through the C ABI) against the CPU oracle and the
+reference-generated golden vectors.
+
+Tolerances: kernel vs fp64 oracle on identically rounded inputs --
+fp16 atol=rtol=2e-3, bf16 atol=rtol=1.6e-2.  The appended K row is compared to one storage ulp
+(on-device sincosf/powf vs numpy differ in the last fp32 bit of the angle); the appended V row
+and everything that is pure data movement must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16bits_to_f32
+from oracle import decode_ref, rotary_table_ref, round_to
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp16": 2e-3, "bf16": 1.6e-2}
+ULP = {"fp16": 2.0 ** -10, "bf16": 2.0 ** -7}
+TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def sfa():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    import starflashattention_amd as m
+    m._lib.load()                  # fail loudly if the HIP library is missing
+    return m
+
+
+def run_decode(sfa, qkv, kc, vc, lens, layer, rot, dtype, num_splits=0, biases=None, tables=None):
+    """numpy fp32 (representable) in -> (o, kc_after, vc_after) numpy fp32 out."""
+    dev = torch.device("cuda:0")
+    dt = TDT[dtype]
+    B, _, H, D = qkv.shape
+    L, M = kc.shape[1], kc.shape[2]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dt).to(dev)
+    qkv_d, kc_d, vc_d = t(qkv), t(kc), t(vc)
+    o = torch.full((B, H, D), 7.0, dtype=dt, device=dev)
+    if biases is None:
+        bq = bk = bv = torch.zeros(0, dtype=dt, device=dev)
+    else:
+        bq, bk, bv = (t(b) for b in biases)
+    kw = {}
+    if tables is not None:
+        kw = dict(rotary_cos_table=t(tables[0]), rotary_sin_table=t(tables[1]))
+    ret = sfa.flash_decode(qkv_d, bq, bk, bv, kc_d, vc_d,
+                           torch.tensor(list(lens), dtype=torch.int32, device=dev), o,
+                           B, M, H, D, rot, M, L, layer, num_splits=num_splits, **kw)
+    assert ret.data_ptr() == o.data_ptr()          # returns the tensor it was given (api:67)
+    torch.cuda.synchronize()
+    return o.float().cpu().numpy(), kc_d.float().cpu().numpy(), vc_d.float().cpu().numpy()
+
+
+def check_against_oracle(sfa, qkv, kc, vc, lens, layer, rot, dtype, **kw):
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    okw = {}
+    if kw.get("biases") is not None:
+        okw = dict(q_bias=kw["biases"][0], k_bias=kw["biases"][1], v_bias=kw["biases"][2])
+    if kw.get("tables") is not None:
+        okw.update(cos_table=kw["tables"][0], sin_table=kw["tables"][1])
+    ref = decode_ref(qkv, kc_ref, vc_ref, lens, layer, rot, dtype=dtype, **okw)
+    o, kc_out, vc_out = run_decode(sfa, qkv, kc, vc, lens, layer, rot, dtype, **kw)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(o, ref["o"], atol=tol, rtol=tol)
+    B = qkv.shape[0]
+    for b in range(B):
+        krow, vrow = kc_out[b, layer, lens[b]], vc_out[b, layer, lens[b]]
+        np.testing.assert_array_equal(vrow, ref["v_row"][b])                 # data movement: exact
+        err = np.abs(krow - ref["k_row"][b])
+        assert np.all(err <= ULP[dtype] * np.maximum(1.0, np.abs(krow)) * 1.01), err.max()
+        assert np.mean(krow == ref["k_row"][b]) > 0.98
+    # nothing else in the caches may change
+    mask = np.ones(kc.shape[:3], bool)
+    for b in range(B):
+        mask[b, layer, lens[b]] = False
+    np.testing.assert_array_equal(kc_out[mask], kc[mask])
+    np.testing.assert_array_equal(vc_out[mask], vc[mask])
+    return o, ref
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("num_splits", [0, 1, 3, 4])
+def test_decode_golden_reference_vectors(sfa, decode_golden, dtype, num_splits):
+    """Every golden case (seq_len around the 32/128 block and split boundaries), against the
+    reference's own outputs."""
+    g = decode_golden
+    qkv = bf16bits_to_f32(g["qkv_bf16bits"])
+    kc = bf16bits_to_f32(g["k_cache_bf16bits"])
+    vc = bf16bits_to_f32(g["v_cache_bf16bits"])
+    layer = int(g["idx_layer"])
+    B, H, D, L, M = (int(x) for x in g["dims"])
+    tag = {"fp16": "f16", "bf16": "bf16"}[dtype]
+    for case, s in enumerate(g["seq_lens"]):
+        lens = [int(s)] * B
+        o, ref = check_against_oracle(sfa, qkv, kc, vc, lens, layer, D, dtype, num_splits=num_splits)
+        # reference evaluated in fp32 on the same 16-bit inputs (it does not round q/k after RoPE)
+        np.testing.assert_allclose(o, g["o_f32"][case], atol=TOL[dtype], rtol=TOL[dtype])
+        # reference evaluated natively in the 16-bit dtype
+        np.testing.assert_allclose(o, g[f"o_{tag}"][case], atol=2 * TOL[dtype], rtol=2 * TOL[dtype])
+
+
+def test_decode_golden_ragged_batch(sfa, decode_golden):
+    g = decode_golden
+    qkv = bf16bits_to_f32(g["qkv_bf16bits"])
+    kc = bf16bits_to_f32(g["k_cache_bf16bits"])
+    vc = bf16bits_to_f32(g["v_cache_bf16bits"])
+    layer = int(g["idx_layer"])
+    D = int(g["dims"][2])
+    lens = [int(g["seq_lens"][3]), int(g["seq_lens"][7])]       # 32 and 129
+    o, _ = check_against_oracle(sfa, qkv, kc, vc, lens, layer, D, "fp16", num_splits=2)
+    np.testing.assert_allclose(o[0], g["o_f32"][3][0], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(o[1], g["o_f32"][7][1], atol=2e-3, rtol=2e-3)
+
+
+def test_decode_partial_rotary_golden(sfa, decode_golden):
+    g = decode_golden
+    qkv = bf16bits_to_f32(g["qkv_bf16bits"])
+    kc = bf16bits_to_f32(g["k_cache_bf16bits"])
+    vc = bf16bits_to_f32(g["v_cache_bf16bits"])
+    layer, rot = int(g["idx_layer"]), int(g["partial_rot_dim"])
+    B, H, D, L, M = (int(x) for x in g["dims"])
+    for case in (0, 4, 8):
+        s = int(g["seq_lens"][case])
+        _, kc_out, _ = run_decode(sfa, qkv, kc, vc, [s] * B, layer, rot, "fp16")
+        want = round_to(g["partial_k_rot_f32"][case], "fp16")
+        got = kc_out[:, layer, s]
+        assert np.all(np.abs(got - want) <= ULP["fp16"] * np.maximum(1.0, np.abs(want)) * 1.01)
+        np.testing.assert_array_equal(got[..., rot:], qkv[:, 1, :, rot:])
+        check_against_oracle(sfa, qkv, kc, vc, [s] * B, layer, rot, "fp16")
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("D,H", [(128, 5), (64, 3)])
+def test_decode_random_shapes(sfa, dtype, D, H):
+    rng = np.random.default_rng(11 + D + H)
+    B, L, M = 3, 2, 700
+    qkv = round_to(rng.standard_normal((B, 3, H, D)), dtype)
+    kc = round_to(rng.standard_normal((B, L, M, H, D)), dtype)
+    vc = round_to(rng.standard_normal((B, L, M, H, D)), dtype)
+    for lens, splits in (([0, 699, 333], 0), ([1, 15, 16], 1), ([64, 65, 63], 5), ([511, 512, 513], 7)):
+        check_against_oracle(sfa, qkv, kc, vc, lens, 0, D, dtype, num_splits=splits)
+        check_against_oracle(sfa, qkv, kc, vc, lens, 1, D // 2, dtype, num_splits=splits)
+        check_against_oracle(sfa, qkv, kc, vc, lens, 1, 0, dtype, num_splits=splits)
+
+
+def test_decode_bias_and_rotary_table(sfa):
+    rng = np.random.default_rng(5)
+    B, H, D, L, M = 2, 4, 128, 1, 300
+    qkv = round_to(rng.standard_normal((B, 3, H, D)), "fp16")
+    kc = round_to(rng.standard_normal((B, L, M, H, D)), "fp16")
+    vc = round_to(rng.standard_normal((B, L, M, H, D)), "fp16")
+    biases = [round_to(0.5 * rng.standard_normal((H, D)), "fp16") for _ in range(3)]
+    check_against_oracle(sfa, qkv, kc, vc, [200, 299], 0, D, "fp16", biases=biases, num_splits=2)
+    # LUT path (the C++ harness's compute_rotary_table): device table == oracle table, then decode
+    cos_d, sin_d = sfa.compute_rotary_table(M, D, torch.float16)
+    cos_r, sin_r = rotary_table_ref(M, D, "fp16")
+    assert np.max(np.abs(cos_d.float().cpu().numpy() - cos_r)) <= 2.0 ** -10
+    assert np.max(np.abs(sin_d.float().cpu().numpy() - sin_r)) <= 2.0 ** -10
+    assert np.mean(cos_d.float().cpu().numpy() == cos_r) > 0.98
+    check_against_oracle(sfa, qkv, kc, vc, [17, 250], 0, D, "fp16", tables=(cos_r, sin_r))
+
+
+def test_decode_ones_known_answer_reference_shapes(sfa, ones_kat):
+    """The reference's only known answer (cc:63-78, 116-129): all ones -> all 1.0, at its own
+    shapes B=2,H=32,D=128,L=4 and (max_seq_len, seq_len) pairs (cc:138-146), fp16, splits=4."""
+    dev = torch.device("cuda:0")
+    B, H, D, L = (int(x) for x in ones_kat["dims_BHDL"])
+    for M, s in ones_kat["max_seq_len__seq_len"]:
+        M, s = int(M), int(s)
+        qkv = torch.ones(B, 3, H, D, dtype=torch.float16, device=dev)
+        kc = torch.ones(B, L, M, H, D, dtype=torch.float16, device=dev)
+        vc = torch.ones(B, L, M, H, D, dtype=torch.float16, device=dev)
+        o = torch.zeros(B, H, D, dtype=torch.float16, device=dev)
+        z = torch.zeros(H, D, dtype=torch.float16, device=dev)
+        sl = torch.full((B,), s, dtype=torch.int32, device=dev)
+        sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, D, M, L, 0, num_splits=4)
+        torch.cuda.synchronize()
+        assert torch.all(o == float(ones_kat["expect"])), (M, s, o.flatten()[:4])
+
+
+def test_decode_rejects_out_of_range_seq_len(sfa, ones_kat):
+    """cc:141-142 pair (4096, 4096) overruns the cache in the reference; here the row is rejected
+    on the device: caches untouched, NaN output, sticky status -> RuntimeError when polled."""
+    dev = torch.device("cuda:0")
+    M, s = (int(x) for x in ones_kat["must_raise"][0])
+    B, H, D, L = 2, 4, 128, 1
+    M = 64
+    qkv = torch.ones(B, 3, H, D, dtype=torch.float16, device=dev)
+    kc = torch.ones(B, L, M, H, D, dtype=torch.float16, device=dev)
+    vc = torch.ones(B, L, M, H, D, dtype=torch.float16, device=dev)
+    guard_k = kc.clone()
+    o = torch.zeros(B, H, D, dtype=torch.float16, device=dev)
+    z = torch.zeros(H, D, dtype=torch.float16, device=dev)
+    sl = torch.tensor([M, 5], dtype=torch.int32, device=dev)       # sample 0 is out of range
+    sfa.check_decode_status(dev)                                    # clean slate
+    for splits in (1, 2):
+        sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, D, M, L, 0, num_splits=splits)
+        with pytest.raises(RuntimeError, match="seq_len"):
+            sfa.check_decode_status(dev)
+        assert torch.isnan(o[0]).all() and torch.all(o[1] == 1.0)
+        assert torch.equal(kc[0], guard_k[0])
+    sfa.check_decode_status(dev)                                    # flag was cleared by the raise
+
+
+def test_decode_argument_errors(sfa):
+    dev = torch.device("cuda:0")
+    B, H, D, L, M = 1, 2, 128, 1, 16
+    mk = lambda *s, dt=torch.float16: torch.zeros(*s, dtype=dt, device=dev)
+    args = lambda **kw: dict(dict(qkv=mk(B, 3, H, D), kc=mk(B, L, M, H, D), vc=mk(B, L, M, H, D),
+                                  sl=mk(B, dt=torch.int32), o=mk(B, H, D)), **kw)
+
+    def call(a, D_=D):
+        z = mk(0)
+        return sfa.flash_decode(a["qkv"], z, z, z, a["kc"], a["vc"], a["sl"], a["o"], B, M, H, D_, D_, M, L, 0)
+
+    call(args())
+    with pytest.raises(RuntimeError, match="dtype"):
+        call(args(o=mk(B, H, D, dt=torch.bfloat16)))
+    with pytest.raises(RuntimeError, match="shape"):
+        call(args(kc=mk(B, L, M + 1, H, D)))
+    with pytest.raises(RuntimeError, match="float16 or bfloat16"):
+        call(args(qkv=mk(B, 3, H, D, dt=torch.float32)))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        call(args(sl=torch.zeros(B, dtype=torch.int32)))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        call(args(o=mk(B, H, 2 * D)[..., ::2]))
+
+
+def test_decode_roundtrip_multi_step_append(sfa):
+    """Size-independent property: decoding T tokens one by one (each step appends its K/V) gives,
+    at the last step, the same output as one causal-attention row computed from scratch."""
+    from oracle import sdpa_ref, rope_interleaved
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda:0")
+    B, H, D, L, M, T = 2, 2, 128, 1, 40, 24
+    toks = round_to(rng.standard_normal((T, B, 3, H, D)), "bf16")
+    kc = torch.zeros(B, L, M, H, D, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    o = torch.zeros(B, H, D, dtype=torch.bfloat16, device=dev)
+    z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
+    for t in range(T):
+        sl = torch.full((B,), t, dtype=torch.int32, device=dev)
+        sfa.flash_decode(torch.from_numpy(toks[t]).bfloat16().to(dev), z, z, z, kc, vc, sl, o,
+                         B, M, H, D, D, M, L, 0)
+    torch.cuda.synchronize()
+    # from scratch on the CPU: rope every token at its own position, attend with the last query
+    K = np.stack([round_to(rope_interleaved(toks[t][:, 1], t, D), "bf16") for t in range(T)], 2)  # [B,H,T,D]
+    V = np.stack([toks[t][:, 2] for t in range(T)], 2)
+    q = round_to(rope_interleaved(toks[T - 1][:, 0], T - 1, D), "bf16")[:, :, None, :]
+    want = sdpa_ref(q, K, V)[:, :, 0]
+    np.testing.assert_allclose(o.float().cpu().numpy(), want, atol=1.6e-2, rtol=1.6e-2)
+    np.testing.assert_array_equal(vc[:, 0, :T].float().cpu().numpy(), V.transpose(0, 2, 1, 3))

@@ -1,0 +1,166 @@
+"""GPU parity of the HIP prefill forward (through the C ABI) against the CPU oracle and the
+golden vectors (PyTorch eager SDPA on the CPU, tests/golden/make_golden.py).
+
+Tolerance: kernel vs fp64 oracle on identically rounded inputs --
+fp16 atol=rtol=2e-3, bf16 atol=rtol=1.6e-2; additionally the kernel's error must stay within 2x
+that of a plain same-dtype PyTorch computation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16bits_to_f32
+from oracle import sdpa_ref, round_to
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp16": 2e-3, "bf16": 1.6e-2}
+TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def sfa():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    import starflashattention_amd as m
+    m._lib.load()
+    return m
+
+
+def run_fwd(sfa, q, k, v, dtype, causal, **kw):
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(TDT[dtype]).to(dev)
+    out = sfa.flash_attn_fwd(t(q), t(k), t(v), causal=causal, **kw)
+    torch.cuda.synchronize()
+    if isinstance(out, tuple):
+        return out[0].float().cpu().numpy(), out[1].cpu().numpy()
+    return out.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["s129_d128", "s200_d64", "gqa_s64_d128"])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_prefill_golden(sfa, prefill_golden, name, causal, dtype):
+    g = prefill_golden
+    q, k, v = (bf16bits_to_f32(g[f"{name}_{t}"]) for t in "qkv")     # representable in both dtypes
+    o = run_fwd(sfa, q, k, v, dtype, causal)
+    want = g[f"{name}_o_{'causal' if causal else 'full'}"]
+    np.testing.assert_allclose(o, want, atol=TOL[dtype], rtol=TOL[dtype])
+
+
+CASES = [  # B, Hq, Hkv, Sq, Sk, D
+    (1, 1, 1, 1, 1, 128),          # single token
+    (2, 3, 3, 64, 64, 128),
+    (1, 2, 2, 256, 256, 128),      # exactly one q-tile, 4 kv tiles
+    (1, 2, 1, 257, 257, 128),      # one row into the second q-tile, GQA
+    (2, 2, 2, 513, 513, 64),
+    (1, 4, 2, 300, 300, 64),
+    (1, 2, 2, 100, 333, 128),      # Sq < Sk: bottom-right aligned causal
+    (1, 1, 1, 333, 100, 128),      # Sq > Sk: the first rows see no key under the causal mask
+    (1, 8, 8, 1024, 1024, 128),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_hq%d_hkv%d_sq%d_sk%d_d%d" % c)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_prefill_vs_oracle(sfa, case, causal, dtype):
+    B, Hq, Hkv, Sq, Sk, D = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    q = round_to(rng.standard_normal((B, Hq, Sq, D)), dtype)
+    k = round_to(rng.standard_normal((B, Hkv, Sk, D)), dtype)
+    v = round_to(rng.standard_normal((B, Hkv, Sk, D)), dtype)
+    want, lse_want = sdpa_ref(q, k, v, causal=causal, return_lse=True)
+    o, lse = run_fwd(sfa, q, k, v, dtype, causal, return_lse=True)
+    np.testing.assert_allclose(o, want, atol=TOL[dtype], rtol=TOL[dtype])
+    fin = np.isfinite(lse_want)
+    np.testing.assert_allclose(lse[fin], lse_want[fin], atol=2e-3, rtol=2e-3)
+    assert np.all(lse[~fin] == -np.inf)
+    # error budget: no worse than 2x a plain same-dtype torch computation on the GPU
+    dev = torch.device("cuda:0")
+    tq, tk, tv = (torch.from_numpy(x).to(TDT[dtype]).to(dev) for x in (q, k, v))
+    g = Hq // Hkv
+    s = torch.matmul(tq, tk.repeat_interleave(g, 1).transpose(-1, -2)) / (D ** 0.5)
+    if causal:
+        i = torch.arange(Sq, device=dev)[:, None]
+        j = torch.arange(Sk, device=dev)[None, :]
+        s = s.masked_fill(~(j <= i + (Sk - Sq)), float("-inf"))
+    p = torch.softmax(s.float(), -1).to(TDT[dtype])
+    plain = torch.nan_to_num(torch.matmul(p, tv.repeat_interleave(g, 1))).float().cpu().numpy()
+    e_kernel = np.abs(o - want).max()
+    e_plain = np.abs(plain - want).max()
+    assert e_kernel <= 2 * e_plain + 1e-3, (e_kernel, e_plain)
+
+
+def test_prefill_strided_layouts_and_out(sfa):
+    """[B,S,H,D]-stored tensors viewed as [B,H,S,D] (the other common layout) and a caller-owned out."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, H, S, D = 2, 3, 200, 128
+    q, k, v = (torch.randn(B, S, H, D, device=dev).bfloat16() for _ in range(3))
+    out_store = torch.zeros(B, S, H, D, device=dev, dtype=torch.bfloat16)
+    o = sfa.flash_attn_fwd(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), causal=True,
+                           out=out_store.transpose(1, 2))
+    o2 = sfa.flash_attn_fwd(q.transpose(1, 2).contiguous(), k.transpose(1, 2).contiguous(),
+                            v.transpose(1, 2).contiguous(), causal=True)
+    torch.cuda.synchronize()
+    assert o.data_ptr() == out_store.data_ptr()
+    assert torch.equal(o, o2)
+    # qkv packed [B,S,3,H,D] slices (stride between q,k,v inside one allocation)
+    qkv = torch.randn(B, S, 3, H, D, device=dev).half()
+    o3 = sfa.flash_attn_fwd(qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2))
+    want = sdpa_ref(*(qkv[:, :, i].transpose(1, 2).float().cpu().numpy() for i in range(3)))
+    np.testing.assert_allclose(o3.float().cpu().numpy(), want, atol=2e-3, rtol=2e-3)
+
+
+def test_prefill_forced_rescale_branch(sfa):
+    """cdna_hip_programming.md rule 26: force the online-softmax max to jump at a chosen tile --
+    one K row far larger than the rest, placed late in the sequence, against every Q row."""
+    rng = np.random.default_rng(9)
+    B, H, S, D = 1, 2, 640, 128
+    q = round_to(rng.standard_normal((B, H, S, D)), "bf16")
+    k = round_to(0.1 * rng.standard_normal((B, H, S, D)), "bf16")
+    v = round_to(rng.standard_normal((B, H, S, D)), "bf16")
+    for spike_at in (5, 200, 639):
+        k2 = k.copy()
+        k2[:, :, spike_at] = round_to(4.0 * np.sign(q[:, :, -1]) , "bf16")   # aligns with the last query
+        for causal in (False, True):
+            want = sdpa_ref(q, k2, v, causal=causal)
+            o = run_fwd(sfa, q, k2, v, "bf16", causal)
+            np.testing.assert_allclose(o, want, atol=1.6e-2, rtol=1.6e-2)
+
+
+def test_prefill_properties_at_bench_size(sfa):
+    """BASELINE configs 2/3 are too large for the CPU oracle, so check size-independent properties
+    at full size: (1) all-equal V rows -> output equals that row exactly-ish (softmax weights sum
+    to 1); (2) causal output row i depends only on keys <= i: truncating the sequence leaves the
+    first rows bit-identical; (3) a spot-checked slice of heads against the oracle."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, H, S, D = 2, 4, 4096, 128
+    q, k, v = (torch.randn(B, H, S, D, device=dev).bfloat16() for _ in range(3))
+    vconst = torch.randn(1, 1, 1, D, device=dev).bfloat16().expand(B, H, S, D).contiguous()
+    o = sfa.flash_attn_fwd(q, k, vconst, causal=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.float().cpu().numpy(), vconst.float().cpu().numpy(), atol=1.6e-2, rtol=1.6e-2)
+    full = sfa.flash_attn_fwd(q, k, v, causal=True)
+    part = sfa.flash_attn_fwd(q[:, :, :1024].contiguous(), k[:, :, :1024].contiguous(),
+                              v[:, :, :1024].contiguous(), causal=True)
+    torch.cuda.synchronize()
+    assert torch.equal(full[:, :, :1024], part)
+    want = sdpa_ref(q[:1, :1].float().cpu().numpy(), k[:1, :1].float().cpu().numpy(),
+                    v[:1, :1].float().cpu().numpy(), causal=True)
+    np.testing.assert_allclose(full[:1, :1].float().cpu().numpy(), want, atol=1.6e-2, rtol=1.6e-2)
+
+
+def test_prefill_argument_errors(sfa):
+    dev = torch.device("cuda:0")
+    q = torch.zeros(1, 2, 16, 128, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="float16 or bfloat16"):
+        sfa.flash_attn_fwd(q.float(), q.float(), q.float())
+    with pytest.raises(RuntimeError, match="dtype"):
+        sfa.flash_attn_fwd(q, q.half(), q)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        z = torch.zeros(1, 2, 16, 96, device=dev, dtype=torch.bfloat16)
+        sfa.flash_attn_fwd(z, z, z)
+    with pytest.raises(RuntimeError, match="heads_q"):
+        sfa.flash_attn_fwd(q.expand(1, 2, 16, 128)[:, :, :, :].repeat(1, 2, 1, 1)[:, :3], q, q)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box via gpurun: smoke -> pytest -m gpu -> short bench.  Each step is bounded by
+# its own timeout; a step that times out or is killed stops the sequence (no GPU work after a hang).
+# Test/assertion failures do not stop later steps (their logs are what we want back).
+set -u
+mkdir -p gpurun_out
+cd "${GRAFT_REPO_ROOT:-.}"
+run_step() {  # name seconds cmd...
+  local name=$1 secs=$2; shift 2
+  echo "== $name" | tee -a gpurun_out/ci.log
+  timeout -k 10 "$secs" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "== $name rc=$rc" | tee -a gpurun_out/ci.log
+  tail -n 15 "gpurun_out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "!! $name timed out/killed: stopping"; exit $rc; fi
+  return 0
+}
+: > gpurun_out/ci.log
+STEPS=${STEPS:-smoke tests bench}
+for s in $STEPS; do
+  case $s in
+    smoke) run_step smoke 300 python __graft_entry__.py smoke ;;
+    tests) run_step tests 900 python -m pytest tests -m gpu -x -q ;;
+    testsall) run_step tests 900 python -m pytest tests -m gpu -q ;;
+    bench) run_step bench 600 python bench.py --steps 10 --warmup 3 ;;
+    benchfast) run_step bench 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode ;;
+    *) run_step "custom" 600 bash -c "$s" ;;
+  esac
+done
