@@ -1,0 +1,49 @@
+// Shared pieces of the gfx950 prefill kernels: tile geometry, the two LDS images and the
+// block -> (head, q-tile) map.  See prefill_v1.hip for the design notes.
+#pragma once
+#include "sfa_device.h"
+#include "sfa_host.h"
+
+namespace sfa {
+namespace prefill {
+
+constexpr int kBM = 256;      // query rows per workgroup
+constexpr int kBN = 64;       // keys per tile
+constexpr int kThreads = 512;
+
+__device__ __forceinline__ float ninf() { return -__builtin_huge_valf(); }
+
+// byte offset of 16-byte chunk `ch` of row `row` inside a [kBN][D] 16-bit LDS tile
+template <int D>
+__device__ __forceinline__ int k_off(int row, int ch) {
+    if (D == 128) return 256 * row + 16 * (ch ^ (row & 15));
+    return 128 * row + 16 * (ch ^ ((row >> 1) & 7));
+}
+template <int D>
+__device__ __forceinline__ int v_off(int row, int ch) {
+    if (D == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return 128 * row + 16 * (ch ^ (((row >> 1) & 1) << 2));
+}
+
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+
+
+// XCD-aware decode of blockIdx.x: XCD x (= bid % 8 under round-robin dispatch; a speed hint only)
+// owns heads [x*bh_per_xcd, (x+1)*bh_per_xcd) and walks each head's q-tiles heaviest-first.
+struct BlockCoord { int bh, qt; };
+__device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    BlockCoord c;
+    c.bh = xcd * p.bh_per_xcd + slot / p.nq_tiles;
+    c.qt = p.nq_tiles - 1 - (slot % p.nq_tiles);
+    return c;
+}
+
+}  // namespace prefill
+
+// one launcher per kernel generation; launch_prefill (prefill_dispatch.hip) picks one
+int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v1(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+
+}  // namespace sfa

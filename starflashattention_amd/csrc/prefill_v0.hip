@@ -20,36 +20,17 @@
 //   * blockIdx -> (head, q-tile) is XCD-aware: the 8 XCDs each own a contiguous range of
 //     (batch, head) pairs, walk a head's q-tiles heaviest-first (causal), so all q-tiles of a
 //     head stream the same K/V through one XCD's L2 at about the same time.
-#include "sfa_device.h"
-#include "sfa_host.h"
+#include "prefill_common.h"
 
 namespace sfa {
 
 namespace {
 
-constexpr int kBM = 256;      // query rows per workgroup
-constexpr int kBN = 64;       // keys per tile
-constexpr int kThreads = 512;
-
-__device__ __forceinline__ float ninf() { return -__builtin_huge_valf(); }
-
-// byte offset of 16-byte chunk `ch` of row `row` inside a [kBN][D] 16-bit LDS tile
-template <int D>
-__device__ __forceinline__ int k_off(int row, int ch) {
-    if (D == 128) return 256 * row + 16 * (ch ^ (row & 15));
-    return 128 * row + 16 * (ch ^ ((row >> 1) & 7));
-}
-template <int D>
-__device__ __forceinline__ int v_off(int row, int ch) {
-    if (D == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-    return 128 * row + 16 * (ch ^ (((row >> 1) & 1) << 2));
-}
-
-typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+using namespace prefill;
 
 template <class Tr, int D, bool CAUSAL>
 __global__ void __launch_bounds__(kThreads, 2)
-prefill_kernel(const PrefillKernelParams p) {
+prefill_kernel_v0(const PrefillKernelParams p) {
     using Vec = typename Tr::mfma_vec;
     constexpr int NKS = D / 16;                 // k-steps of Q.K^T
     constexpr int NDB = D / 32;                 // 32-wide d blocks of O^T
@@ -259,23 +240,23 @@ int launch_prefill_t(const PrefillKernelParams &p, bool causal, hipStream_t stre
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v0<Tr, D, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v0<Tr, D, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (causal) {
-        hipLaunchKernelGGL((prefill_kernel<Tr, D, true>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel_v0<Tr, D, true>), grid, block, lds, stream, p);
     } else {
-        hipLaunchKernelGGL((prefill_kernel<Tr, D, false>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel_v0<Tr, D, false>), grid, block, lds, stream, p);
     }
-    return check_launch("prefill_kernel");
+    return check_launch("prefill_kernel_v0");
 }
 
 }  // namespace
 
-int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_prefill_t<Fp16, 128>(p, causal, stream);
         if (head_dim == 64) return launch_prefill_t<Fp16, 64>(p, causal, stream);

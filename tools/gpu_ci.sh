@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 run_step() {  # name seconds cmd...
   local name=$1 secs=$2; shift 2
   echo "== $name" | tee -a gpurun_out/ci.log
-  timeout -k 10 "$secs" "$@" > "gpurun_out/$name.log" 2>&1
+  timeout -k 10 "$secs" "$@" > "gpurun_out/$name.log" 2>&1 < /dev/null
   local rc=$?
   echo "== $name rc=$rc" | tee -a gpurun_out/ci.log
   tail -n 15 "gpurun_out/$name.log"
@@ -20,10 +20,14 @@ STEPS=${STEPS:-smoke tests bench}
 for s in $STEPS; do
   case $s in
     smoke) run_step smoke 300 python __graft_entry__.py smoke ;;
-    tests) run_step tests 900 python -m pytest tests -m gpu -x -q ;;
-    testsall) run_step tests 900 python -m pytest tests -m gpu -q ;;
+    tests) run_step tests 900 python -u -m pytest tests -m gpu -x -q --timeout 120 ;;
+    testsall) run_step tests 900 python -u -m pytest tests -m gpu -q --timeout 120 ;;
     bench) run_step bench 600 python bench.py --steps 10 --warmup 3 ;;
     benchfast) run_step bench 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode ;;
-    *) run_step "custom" 600 bash -c "$s" ;;
+    prefill) run_step prefill 300 python -u -m pytest tests/test_prefill_gpu.py -m gpu -x -q --timeout 120 ;;
+    decode) run_step decode 300 python -u -m pytest tests/test_decode_gpu.py -m gpu -x -q --timeout 120 ;;
+    ab) run_step ab 300 python -u tools/prefill_ab.py ${AB_ARGS:-0 1} ;;
+    cmd) run_step cmd ${CMD_TIMEOUT:-300} bash -c "$CMD" < /dev/null ;;
+    *) echo "unknown step $s"; exit 2 ;;
   esac
 done

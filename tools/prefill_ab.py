@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""In-process A/B of the prefill kernel generations at the headline shape (interleaved rounds,
+cdna_hip_programming.md rule 24).  usage: python tools/prefill_ab.py [impl ...] [--noncausal] [--d64]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import starflashattention_amd as sfa
+
+impls = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [0, 1]
+causal = "--noncausal" not in sys.argv
+D = 64 if "--d64" in sys.argv else 128
+B, H, S = 16, 32, 4096
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(1)
+q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).bfloat16() for _ in range(3))
+outs = {}
+flops = 4.0 * B * H * S * S * D / (2 if causal else 1)
+def run(impl, n):
+    os.environ["SFA_PREFILL_IMPL_DYNAMIC"] = str(impl)
+    o = torch.empty_like(q)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        sfa.flash_attn_fwd(q, k, v, causal=causal, out=o)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, o
+for i in impls:
+    run(i, 3)
+res = {i: [] for i in impls}
+for rnd in range(5):
+    for i in impls:
+        ms, o = run(i, 5)
+        res[i].append(ms); outs[i] = o
+ref = outs[impls[0]].float()
+for i in impls:
+    ms = sorted(res[i]); med = ms[len(ms)//2]
+    err = (outs[i].float() - ref).abs().max().item()
+    print(f"impl {i}: median {med:.3f} ms  min {ms[0]:.3f} ms  {flops/med/1e9:.1f} TFLOPS (best {flops/ms[0]/1e9:.1f})  max|diff vs impl {impls[0]}| = {err:.4g}", flush=True)
