@@ -45,5 +45,6 @@ __device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) 
 // one launcher per kernel generation; launch_prefill (prefill_dispatch.hip) picks one
 int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_v1(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 
 }  // namespace sfa

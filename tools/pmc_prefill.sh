@@ -1,0 +1,16 @@
+#!/bin/bash
+# PMC passes over the headline prefill kernel (run on the GPU box).  Counters in their own
+# runs, no trace domains besides kernel-trace (gpurun refuses other combinations).
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+OUT=$PWD/gpurun_out/pmc; mkdir -p $OUT
+export SFA_PREFILL_IMPL=${IMPL:-1}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $OUT/counters.txt 2>&1 < /dev/null
+i=0
+for set in "${@}"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python $GRAFT_REPO_ROOT/tools/prefill_once.py > $OUT/pass$i.log 2>&1 < /dev/null
+  echo "pass $i ($set) rc=$?"
+done
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | tee $OUT/summary.txt
