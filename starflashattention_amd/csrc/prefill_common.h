@@ -46,5 +46,9 @@ __device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) 
 int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_v1(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_v2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v3(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_ablation(const PrefillKernelParams &p, int abl, int dtype, int head_dim, bool causal,
+                            hipStream_t stream);
 
 }  // namespace sfa

@@ -10,13 +10,16 @@ namespace sfa {
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     static const int impl = [] {
         const char *e = std::getenv("SFA_PREFILL_IMPL");
-        return e ? std::atoi(e) : 2;
+        return e ? std::atoi(e) : 3;
     }();
     const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // A/B harness only: re-read every call
     const int which = e ? std::atoi(e) : impl;
+    if (which >= 100) return launch_prefill_ablation(p, which - 100, dtype, head_dim, causal, stream);
     if (which == 0) return launch_prefill_v0(p, dtype, head_dim, causal, stream);
     if (which == 1) return launch_prefill_v1(p, dtype, head_dim, causal, stream);
-    return launch_prefill_v2(p, dtype, head_dim, causal, stream);
+    if (which == 2) return launch_prefill_v2(p, dtype, head_dim, causal, stream);
+    if (which == 4) return launch_prefill_v4(p, dtype, head_dim, causal, stream);
+    return launch_prefill_v3(p, dtype, head_dim, causal, stream);
 }
 
 }  // namespace sfa
