@@ -23,7 +23,7 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB_NAME = "libStarFlashAttention.so"
 ARCH = "gfx950"
 
-KERNEL_SOURCES = ["decode_kernel.hip", "prefill_v0.hip", "prefill_v1.hip", "prefill_v2.hip", "prefill_v3.hip", "prefill_dispatch.hip", "aux_kernels.hip", "c_api.hip",
+KERNEL_SOURCES = ["decode_kernel.hip", "prefill_v0.hip", "prefill_v1.hip", "prefill_v2.hip", "prefill_v3.hip", "prefill_v5.hip", "prefill_dispatch.hip", "aux_kernels.hip", "c_api.hip",
                   "cxx_surface.hip"]
 
 

@@ -48,6 +48,8 @@ int launch_prefill_v1(const PrefillKernelParams &p, int dtype, int head_dim, boo
 int launch_prefill_v2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_v3(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_v4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v5(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_v6(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_ablation(const PrefillKernelParams &p, int abl, int dtype, int head_dim, bool causal,
                             hipStream_t stream);
 

@@ -10,7 +10,7 @@ namespace sfa {
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     static const int impl = [] {
         const char *e = std::getenv("SFA_PREFILL_IMPL");
-        return e ? std::atoi(e) : 3;
+        return e ? std::atoi(e) : 5;
     }();
     const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // A/B harness only: re-read every call
     const int which = e ? std::atoi(e) : impl;
@@ -18,6 +18,8 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     if (which == 0) return launch_prefill_v0(p, dtype, head_dim, causal, stream);
     if (which == 1) return launch_prefill_v1(p, dtype, head_dim, causal, stream);
     if (which == 2) return launch_prefill_v2(p, dtype, head_dim, causal, stream);
+    if (which == 5) return launch_prefill_v5(p, dtype, head_dim, causal, stream);
+    if (which == 6) return launch_prefill_v6(p, dtype, head_dim, causal, stream);
     if (which == 4) return launch_prefill_v4(p, dtype, head_dim, causal, stream);
     return launch_prefill_v3(p, dtype, head_dim, causal, stream);
 }

@@ -108,9 +108,11 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     constexpr int EM = 32 / NPV;            // new scores max-ed per late PV slot
 
     auto ld_k = [&](int ks) -> Vec {
+        if (ABL & 16) return kpre[0];       // timing-only ablation: no K fragment reads
         return bitcast<Vec>(*reinterpret_cast<const uint4 *>(kb + KS * 32 * HN + 32 * ks));
     };
     auto ld_v = [&](int j) -> Vec {         // A operand of PV MFMA j: d block j % NDB, k-step j / NDB
+        if (ABL & 16) return kpre[1];       // timing-only ablation: no V fragment reads
         const int d = j % NDB, k = j / NDB;
         const i16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (lds_i16x4 *)(vb + VS * 16 * (2 * HO + k) + 64 * d));
@@ -446,16 +448,16 @@ int launch_pf(const PrefillKernelParams &p, int dtype, int head_dim, bool causal
 }
 
 // timing-only ablations of the headline configuration (bf16, D=128); results are WRONG by design
-template <int ABL>
+template <int ABL, int PF = 2>
 int launch_abl(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     const size_t lds = Lds<128>::TOTAL;
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v3<Bf16, 128, true, 2, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v3<Bf16, 128, true, PF, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v3<Bf16, 128, false, 2, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v3<Bf16, 128, false, PF, ABL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (causal) hipLaunchKernelGGL((prefill_kernel_v3<Bf16, 128, true, 2, ABL>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((prefill_kernel_v3<Bf16, 128, false, 2, ABL>), grid, block, lds, stream, p);
+    if (causal) hipLaunchKernelGGL((prefill_kernel_v3<Bf16, 128, true, PF, ABL>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((prefill_kernel_v3<Bf16, 128, false, PF, ABL>), grid, block, lds, stream, p);
     return check_launch("prefill_kernel_v3 (ablation)");
 }
 
@@ -472,6 +474,11 @@ int launch_prefill_ablation(const PrefillKernelParams &p, int abl, int dtype, in
         case 5: return launch_abl<5>(p, causal, stream);
         case 8: return launch_abl<8>(p, causal, stream);
         case 13: return launch_abl<13>(p, causal, stream);
+        case 29: return launch_abl<29>(p, causal, stream);          // + no LDS fragment reads
+        case 213: return launch_abl<13, 4>(p, causal, stream);      // ablation 13 at PF = 4
+        case 313: return launch_abl<13, 6>(p, causal, stream);      // ablation 13 at PF = 6
+        case 200: return launch_abl<0, 4>(p, causal, stream);       // full kernel at PF = 4 (correct)
+        case 300: return launch_abl<0, 6>(p, causal, stream);       // full kernel at PF = 6 (correct)
         default: return fail(SFA_ERR_BAD_SHAPE, "no ablation build %d", abl);
     }
 }

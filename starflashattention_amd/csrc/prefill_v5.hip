@@ -1,0 +1,532 @@
+// Fused attention forward (prefill) for gfx950 (MI355X), generation 5: half-tile software
+// pipeline, explicitly slot-ordered, NQB query blocks per wave.
+// bf16 / fp16, head_dim 64 / 128, causal or full, MHA or GQA.  The reference has no prefill
+// kernel; this is the entry point BASELINE.json's headline metric is quoted on (SURVEY.md
+// section 8(a) row A-new).
+//
+// MI355X design (MFMA-bound: AI = 1024 FLOP/B at S=4096, D=128):
+//   * workgroup = 256 query rows of one (batch, head).  NQB = 2: 4 waves, one per SIMD, each
+//     owning 64 rows (two 32-row query blocks) and the whole 512-register file; NQB = 1: 8 waves
+//     of 32 rows at two waves per SIMD.  With NQB = 2 every K / V fragment read from LDS feeds TWO
+//     MFMAs, which halves the LDS operand traffic (1 KB per MFMA at NQB = 1 -- measured to be
+//     what holds that variant at ~55 % MFMA utilisation even with all softmax work removed).
+//   * K/V tiles of 64 keys are staged once per workgroup into LDS (register-staged: global loads
+//     in flight for a whole tile time, then ds_write; K double-, V triple-buffered; ONE barrier
+//     per tile) and shared by all waves.
+//   * S^T = K . Q^T with v_mfma_f32_32x32x16 (A = K rows from LDS by ds_read_b128, B = Q^T held
+//     in registers for the whole kernel): the 32x32 accumulator has the QUERY on the lane and
+//     keys in registers, so the online-softmax row max / row sum are in-lane loops plus one
+//     v_permlane32_swap -- no LDS, no ds_bpermute.
+//   * O^T += V^T . P^T: the S^T accumulator, exponentiated and converted to 16 bit in place, is
+//     already the B operand of the second MFMA (it sums over the accumulator's row index);
+//     A = V^T comes from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose).
+//     The O^T accumulator again has the query on the lane: the rescale is one scalar per lane.
+//   * Software pipeline at HALF-tile (32-key) granularity inside each wave (MFMA and VALU are
+//     separate pipes).  Per query block two 16-register score accumulators A (keys 0-31 of a
+//     tile) and B (keys 32-63) alternate roles:
+//        H1(t): QK^T(B_t)     || max,exp(A_t),   PV(A_t) || lane max(B_t)
+//        H2(t): QK^T(A_{t+1}) || max,exp(B_t),   PV(B_t) || lane max(A_{t+1})
+//   * Every half-step is written as SLOTS in program order -- one LDS fragment, the NQB MFMAs
+//     it feeds, the fragment read PF slots ahead, and a slice of the softmax VALU work -- fenced
+//     with sched_barrier(0) so hipcc keeps that order (its own clustering hoisted 50+ fragment
+//     registers, spilled, and a spill reload's vmcnt(0) drained the in-flight staging loads).
+//   * Lazy rescale: O and the row sum are rescaled only when some row max in the wave grew by
+//     more than 2^8 over the reference max (wave-uniform branch, almost never taken after the
+//     first tiles).  exp2 arguments stay <= 8, so P <= 256: bf16/fp16 keep the same RELATIVE
+//     precision and the fp32 accumulators have ample headroom.
+//   * LDS images use PADDED rows (prefill_common.h would XOR-swizzle): every read address is one
+//     lane-constant base plus a compile-time immediate -- two LDS address registers in total --
+//     and SQ_LDS_BANK_CONFLICT measures 0.
+//   * blockIdx -> (head, q-tile) is XCD-aware (prefill_common.h).
+#include "prefill_common.h"
+
+namespace sfa {
+
+namespace {
+
+using namespace prefill;
+
+constexpr float kRescaleThr = 8.0f;     // log2 units
+
+//   K rows: 2*D + 16 bytes.  ds_read_b128 lane groups read 16 rows (distinct mod 16) at one chunk:
+//           slot = (17*row + ch) mod 16 (D=128), (9*row + ch) mod 16 (D=64) -> conflict-free.
+//   V rows: 2*D + 64 bytes.  a 32-lane half of ds_read_b64_tr_b16 reads 4 consecutive rows x 64
+//           contiguous bytes: 320q mod 256 = 64q (D=128), 192q mod 256 = {0,192,128,64} (D=64)
+//           -> the four rows tile the 256-byte bank row, conflict-free.
+template <int D> struct Lds {
+    static constexpr int KS = 2 * D + 16;           // K row stride (bytes)
+    static constexpr int VS = 2 * D + 64;           // V row stride
+    static constexpr int KTILE = kBN * KS;
+    static constexpr int VTILE = kBN * VS;
+    static constexpr int V_BASE = 2 * KTILE;        // K[2] then V[3]
+    static constexpr int TOTAL = 2 * KTILE + 3 * VTILE;
+    static_assert(3 * VTILE < 65536 && 2 * KTILE < 65536, "ds immediates are 16 bit");
+};
+
+// key of register r = kbase + (r&3) + 8*(r>>2) + 4*h2
+__device__ __forceinline__ void mask_half(f32x16 &s, int kbase, int h2, int lim) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (kbase + (r & 3) + 8 * (r >> 2) + 4 * h2 > lim) s[r] = ninf();
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+__device__ __forceinline__ float lane_rowmax(const f32x16 &s) {
+    float m0 = max3(s[0], s[1], s[2]), m1 = max3(s[3], s[4], s[5]);
+    m0 = max3(m0, s[6], s[7]);
+    m1 = max3(m1, s[8], s[9]);
+    m0 = max3(m0, s[10], s[11]);
+    m1 = max3(m1, s[12], s[13]);
+    return fmaxf(max3(m0, s[14], s[15]), m1);
+}
+
+#define SFA_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Per-wave online-softmax state of NQB query blocks.
+template <int D, int NQB>
+struct Acc {
+    f32x16 o[NQB][D / 32];      // O^T accumulators
+    float msc[NQB];             // reference max the exponentials are taken against (log2 units)
+    float lsum[NQB];            // this lane's share of the running row sum
+};
+
+// One pipelined half-step in explicit slot order, for all NQB query blocks of the wave:
+//   sN[q] <- scores of K rows [32*HN, +32) of the tile at kb             (DO_QK; NKS*NQB MFMAs)
+//   sO[q]  = scores of keys [32*HO, +32) of the tile whose V is at vb: row max finished (slot 0),
+//            exponentiated in place, packed to 16 bit, O^T += V^T . P^T  (NPV*NQB MFMAs)
+// kb / vb / kb_pref already include this lane's read base (Lds<D> comment).
+//   kpre[PF]  in: first PF K fragments of this half-step (read from LDS earlier);
+//             out (PREF): first PF fragments of the next half-step, rows [32*(1-HN), +32) at kb_pref
+//   mxO[q]    in: this lane's max over the 16 scores in sO[q] (before masking)
+//   mxN[q]    out: this lane's max over the 16 new scores
+//   mask_o    bit q set: sO[q] holds keys that must be masked (diagonal / ragged tiles)
+//   PF        how many slots ahead of its MFMAs a fragment is read
+template <class Tr, int D, int NQB, int PF, int HN, int HO, bool DO_QK, bool PREF>
+__device__ __forceinline__ void h_block(const char *kb, const char *vb, const char *kb_pref,
+                                        const typename Tr::mfma_vec (&qf)[NQB][D / 16],
+                                        f32x16 (&sN)[NQB], f32x16 (&sO)[NQB], Acc<D, NQB> &acc, float c2,
+                                        const float (&mxO)[NQB], float (&mxN)[NQB], int mask_o, int kbase_o,
+                                        int h2, const int (&lim)[NQB], typename Tr::mfma_vec (&kpre)[PF]) {
+    using Vec = typename Tr::mfma_vec;
+    constexpr int NKS = D / 16, NDB = D / 32, NPV = 2 * NDB;
+    constexpr int KS = Lds<D>::KS, VS = Lds<D>::VS;
+    constexpr int EP = 16 / NPV;            // elements per early PV slot     (elements 8..15)
+    constexpr int EM = 32 / NPV;            // new scores max-ed per late PV slot
+
+    auto ld_k = [&](int ks) -> Vec {
+        return bitcast<Vec>(*reinterpret_cast<const uint4 *>(kb + KS * 32 * HN + 32 * ks));
+    };
+    auto ld_v = [&](int j) -> Vec {         // A operand of PV MFMAs j: d block j % NDB, k-step j / NDB
+        const int d = j % NDB, k = j / NDB;
+        const i16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_i16x4 *)(vb + VS * 16 * (2 * HO + k) + 64 * d));
+        const i16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_i16x4 *)(vb + VS * (16 * (2 * HO + k) + 8) + 64 * d));
+        u32x4 av;
+        const u32x2 a_lo = bitcast<u32x2>(t0), a_hi = bitcast<u32x2>(t1);
+        av[0] = a_lo[0]; av[1] = a_lo[1]; av[2] = a_hi[0]; av[3] = a_hi[1];
+        return bitcast<Vec>(av);
+    };
+
+    Vec kf[NKS], vf[NPV];
+    // ---- slot 0: first QK MFMAs next to the finish of sO's row max ----
+    if (DO_QK) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) kf[i] = kpre[i];
+        if (PF < NKS) kf[PF] = ld_k(PF); else vf[PF - NKS] = ld_v(PF - NKS);
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[0], qf[q][0], z);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) vf[i] = ld_v(i);
+    }
+    float msafe[NQB];
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        float mxl = mxO[q];
+        if (mask_o & (1 << q)) {                        // wave-uniform, diagonal / ragged tiles only
+            mask_half(sO[q], kbase_o, h2, lim[q]);
+            mxl = lane_rowmax(sO[q]);
+        }
+        const float mx = half_max(mxl) * c2;            // both lane halves hold the same query
+        if (__any(mx > acc.msc[q] + kRescaleThr)) {     // rare after the first tiles
+            const float mnew = fmaxf(acc.msc[q], mx);
+            const float alpha = (mnew == ninf()) ? 1.0f : fast_exp2(acc.msc[q] - mnew);
+            acc.msc[q] = mnew;
+            acc.lsum[q] *= alpha;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.o[q][d][r] *= alpha;
+        }
+        msafe[q] = (acc.msc[q] == ninf()) ? 0.f : acc.msc[q];
+    }
+    SFA_FENCE();
+
+    uint32_t pk[NQB][8];                    // P^T packed: pk[q][4k .. 4k+3] is the B operand of k-step k
+    float rs0[NQB], rs1[NQB];
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) { rs0[q] = 0.f; rs1[q] = 0.f; }
+    auto soft1 = [&](int e) {               // element e of every query block; packs completed pairs
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            sO[q][e] = fast_exp2(fmaf(sO[q][e], c2, -msafe[q]));
+            if (e & 1) { rs1[q] += sO[q][e]; pk[q][e >> 1] = Tr::pack2(sO[q][e - 1], sO[q][e]); }
+            else { rs0[q] += sO[q][e]; }
+        }
+    };
+
+    if (DO_QK) {
+#pragma unroll
+        for (int i = 1; i < NKS; ++i) {     // elements 0..7 spread over slots 1..NKS-1
+            if (i + PF < NKS) kf[i + PF] = ld_k(i + PF); else vf[i + PF - NKS] = ld_v(i + PF - NKS);
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[i], qf[q][i], sN[q]);
+#pragma unroll
+            for (int e = (i - 1) * 8 / (NKS - 1); e < i * 8 / (NKS - 1); ++e) soft1(e);
+            SFA_FENCE();
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) soft1(e);
+        SFA_FENCE();
+    }
+    float m0[NQB], m1[NQB];
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) { m0[q] = ninf(); m1[q] = ninf(); }
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+        if (j + PF < NPV) {
+            vf[j + PF] = ld_v(j + PF);
+        } else if (PREF) {                  // last PF slots: first K fragments of the next half-step
+            kpre[j + PF - NPV] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(
+                kb_pref + KS * 32 * (1 - HN) + 32 * (j + PF - NPV)));
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            uint4 w;
+            w.x = pk[q][4 * (j / NDB) + 0]; w.y = pk[q][4 * (j / NDB) + 1];
+            w.z = pk[q][4 * (j / NDB) + 2]; w.w = pk[q][4 * (j / NDB) + 3];
+            acc.o[q][j % NDB] = Tr::mfma32(vf[j], bitcast<Vec>(w), acc.o[q][j % NDB]);
+        }
+        if (j < NPV / 2) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) soft1(8 + EP * j + e);
+        } else if (DO_QK) {
+#pragma unroll
+            for (int q = 0; q < NQB; ++q)
+#pragma unroll
+                for (int e = 0; e < EM; e += 4) {
+                    const int r = EM * (j - NPV / 2) + e;
+                    m0[q] = max3(m0[q], sN[q][r], sN[q][r + 1]);
+                    m1[q] = max3(m1[q], sN[q][r + 2], sN[q][r + 3]);
+                }
+        }
+        SFA_FENCE();
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        acc.lsum[q] += rs0[q] + rs1[q];
+        mxN[q] = fmaxf(m0[q], m1[q]);
+    }
+}
+
+template <class Tr, int D, bool CAUSAL, int NQB, int PF>
+__global__ void __launch_bounds__(kThreads / NQB, 2 / NQB)
+prefill_kernel_v5(const PrefillKernelParams p) {
+    using Vec = typename Tr::mfma_vec;
+    constexpr int THREADS = kThreads / NQB;     // 512 (8 waves) or 256 (4 waves)
+    constexpr int WROWS = 32 * NQB;             // query rows per wave
+    constexpr int NKS = D / 16;                 // k-steps of Q.K^T
+    constexpr int NDB = D / 32;                 // 32-wide d blocks of O^T
+    constexpr int CPR = D / 8;                  // 16-B chunks per row
+    constexpr int NLD = kBN * CPR / THREADS;    // chunks staged per thread per tile (1, 2 or 4)
+    constexpr int ROWSTEP = THREADS / CPR;      // row distance between a thread's chunks
+    using L = Lds<D>;
+    static_assert(NLD >= 1 && NLD <= 4, "staging registers are named kr0..kr3");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const BlockCoord bc = block_coord(p);
+    if (bc.bh >= p.B * p.Hq) return;
+    const int b = bc.bh / p.Hq, h = bc.bh % p.Hq;
+    const int hk = h / (p.Hq / p.Hkv);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int q0 = bc.qt * kBM;
+    const int wq0 = q0 + WROWS * wave;          // this wave's first query row
+    const int coff = p.Sk - p.Sq;               // causal: key j visible iff j <= i + coff
+
+    // ---- Q^T fragments (B operand): lane holds Q[row][16ks + 8*h2 .. +8] of each query block ----
+    Vec qf[NQB][NKS];
+    int lim[NQB];                               // last visible key of this lane's row, per block
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        const int qrow = wq0 + 32 * q + l31;
+        const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (long long)min(qrow, p.Sq - 1) * p.qs[2] + 8 * h2;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[q][ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
+        lim[q] = CAUSAL ? min(p.Sk - 1, qrow + coff) : p.Sk - 1;
+    }
+
+    // tiles the workgroup walks / tiles this wave computes on (both wave-uniform)
+    int kv_end = p.Sk;
+    if (CAUSAL) kv_end = min(p.Sk, q0 + kBM + coff);
+    const int nt = kv_end > 0 ? (kv_end + kBN - 1) / kBN : 0;
+    int ntw = nt;
+    if (CAUSAL) ntw = (wq0 + WROWS - 1 + coff >= 0) ? min(nt, (wq0 + WROWS - 1 + coff) / kBN + 1) : 0;
+
+    // ---- staging: thread owns chunks (row st_row + i*ROWSTEP, chunk st_ch), i < NLD, of every tile ----
+    const int st_row = tid / CPR, st_ch = tid % CPR;
+    const char *const kg = reinterpret_cast<const char *>(p.k + b * p.ks[0] + hk * p.ks[1]);   // uniform
+    const char *const vg = reinterpret_cast<const char *>(p.v + b * p.vs[0] + hk * p.vs[1]);
+    const long long k_tile_bytes = 2ll * kBN * p.ks[2], v_tile_bytes = 2ll * kBN * p.vs[2];
+    const unsigned k_rowb = (unsigned)(2 * p.ks[2]), v_rowb = (unsigned)(2 * p.vs[2]);
+    char *const k_w = smem + L::KS * st_row + 16 * st_ch;
+    char *const v_w = smem + L::V_BASE + L::VS * st_row + 16 * st_ch;
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;   // plain scalars: arrays of these ended up in scratch
+    kr0 = kr1 = kr2 = kr3 = vr0 = vr1 = vr2 = vr3 = make_uint4(0, 0, 0, 0);
+
+    // Load this thread's chunks of tile KT.  Whole tiles: uniform tile base + 32-bit lane offset
+    // (no per-load 64-bit VALU math).  The ragged last tile (and the row-clamped dummy tiles the
+    // pipeline requests past the end) clamp every row to Sk-1.
+#define SFA_LD1(DST, G, ROWB, TB, I, KT)                                                            \
+    DST = *reinterpret_cast<const uint4 *>(                                                         \
+        (G) + (KT) * (TB) + (unsigned)(st_row + (I) * ROWSTEP) * (ROWB) + 16u * st_ch)
+#define SFA_LD1C(DST, G, ROWB, I, KT)                                                               \
+    DST = *reinterpret_cast<const uint4 *>(                                                         \
+        (G) + (long long)min((KT) * kBN + st_row + (I) * ROWSTEP, p.Sk - 1) * (ROWB) + 16u * st_ch)
+#define SFA_LOAD_KV(KT)                                                                             \
+    do {                                                                                            \
+        const int kt_ = (KT);                                                                       \
+        if ((kt_ + 1) * kBN <= p.Sk) {                                                              \
+            SFA_LD1(kr0, kg, k_rowb, k_tile_bytes, 0, kt_);                                         \
+            SFA_LD1(vr0, vg, v_rowb, v_tile_bytes, 0, kt_);                                         \
+            if (NLD > 1) { SFA_LD1(kr1, kg, k_rowb, k_tile_bytes, 1, kt_); SFA_LD1(vr1, vg, v_rowb, v_tile_bytes, 1, kt_); } \
+            if (NLD > 2) { SFA_LD1(kr2, kg, k_rowb, k_tile_bytes, 2, kt_); SFA_LD1(vr2, vg, v_rowb, v_tile_bytes, 2, kt_); } \
+            if (NLD > 3) { SFA_LD1(kr3, kg, k_rowb, k_tile_bytes, 3, kt_); SFA_LD1(vr3, vg, v_rowb, v_tile_bytes, 3, kt_); } \
+        } else {                                                                                    \
+            SFA_LD1C(kr0, kg, k_rowb, 0, kt_);                                                      \
+            SFA_LD1C(vr0, vg, v_rowb, 0, kt_);                                                      \
+            if (NLD > 1) { SFA_LD1C(kr1, kg, k_rowb, 1, kt_); SFA_LD1C(vr1, vg, v_rowb, 1, kt_); }  \
+            if (NLD > 2) { SFA_LD1C(kr2, kg, k_rowb, 2, kt_); SFA_LD1C(vr2, vg, v_rowb, 2, kt_); }  \
+            if (NLD > 3) { SFA_LD1C(kr3, kg, k_rowb, 3, kt_); SFA_LD1C(vr3, vg, v_rowb, 3, kt_); }  \
+        }                                                                                           \
+    } while (0)
+#define SFA_STORE_KV(KBUF, VBUF)                                                                    \
+    do {                                                                                            \
+        *reinterpret_cast<uint4 *>(k_w + (KBUF)) = kr0;         /* KBUF/VBUF: byte offsets */       \
+        *reinterpret_cast<uint4 *>(v_w + (VBUF)) = vr0;                                             \
+        if (NLD > 1) {                                                                              \
+            *reinterpret_cast<uint4 *>(k_w + (KBUF) + ROWSTEP * L::KS) = kr1;                        \
+            *reinterpret_cast<uint4 *>(v_w + (VBUF) + ROWSTEP * L::VS) = vr1;                        \
+        }                                                                                           \
+        if (NLD > 2) {                                                                              \
+            *reinterpret_cast<uint4 *>(k_w + (KBUF) + 2 * ROWSTEP * L::KS) = kr2;                    \
+            *reinterpret_cast<uint4 *>(v_w + (VBUF) + 2 * ROWSTEP * L::VS) = vr2;                    \
+        }                                                                                           \
+        if (NLD > 3) {                                                                              \
+            *reinterpret_cast<uint4 *>(k_w + (KBUF) + 3 * ROWSTEP * L::KS) = kr3;                    \
+            *reinterpret_cast<uint4 *>(v_w + (VBUF) + 3 * ROWSTEP * L::VS) = vr3;                    \
+        }                                                                                           \
+    } while (0)
+
+    Acc<D, NQB> acc;
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.o[q][d][r] = 0.f;
+        acc.msc[q] = ninf();
+        acc.lsum[q] = 0.f;
+    }
+    const float c2 = p.scale_log2;
+    // the two LDS read bases of this lane (everything else is an immediate)
+    const char *const k_rd = smem + L::KS * l31 + 16 * h2;                 // K row l31, chunk h2
+    const char *const v_rd = smem + L::V_BASE + L::VS * (4 * h2 + ((lane & 15) >> 2)) +
+                             32 * ((lane >> 4) & 1) + 16 * ((lane & 3) >> 1) + 8 * (lane & 1);
+
+    // bit q set: the 32 keys starting at KBASE need masking for query block q (wave-uniform)
+    auto mask_bits = [&](int kbase) -> int {
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < NQB; ++q)
+            if ((CAUSAL && (kbase + 31 > wq0 + 32 * q + coff)) || (kbase + 32 > p.Sk)) m |= 1 << q;
+        return m;
+    };
+
+    // ---- prologue: tile 0 into LDS, tile 1 in flight, scores of the first half-tile ----
+    f32x16 sA[NQB], sB[NQB];
+    float mxA[NQB], mxB[NQB];                   // lane-local maxima of the pending score half-tiles
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sA[q][r] = 0.f; sB[q][r] = 0.f; }
+        mxA[q] = ninf();
+        mxB[q] = ninf();
+    }
+    if (nt > 0) {
+        SFA_LOAD_KV(0);
+        SFA_STORE_KV(0, 0);
+    }
+    __syncthreads();
+    SFA_LOAD_KV(1);
+    Vec kpre[PF];                               // first PF K fragments of the next half-step
+#pragma unroll
+    for (int i = 0; i < PF; ++i) kpre[i] = bitcast<Vec>(make_uint4(0, 0, 0, 0));
+    if (ntw > 0) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const Vec a = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + 32 * ks));
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) sA[q] = Tr::mfma32(a, qf[q][ks], sA[q]);
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            kpre[i] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + L::KS * 32 + 32 * i));
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) mxA[q] = lane_rowmax(sA[q]);
+    }
+
+    // Tile t lives in K buffer t % 2 and V buffer t % 3 (offsets kept as scalars, added to the two
+    // lane bases once per step).  Buffer safety with ONE barrier per tile: K(t+1) overwrites
+    // K(t-1), last read in H1(t-1), i.e. before barrier(t-1); V(t+1) overwrites V(t-2), last
+    // read in H2(t-2), i.e. before barrier(t-1) as well.  Loads/stores of tiles past the end are
+    // row-clamped and land in buffers nobody reads again.
+    int kcur = 0, vcur = 0;         // byte offsets of tile t's buffers
+    // Stage tile t+1 (loaded one step ago), sync, read the first K fragments of H2, put tile t+2
+    // in flight.
+#define SFA_STAGE_AND_SYNC(T, WITH_KF)                                                              \
+    do {                                                                                            \
+        const int vnext_ = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;                            \
+        SFA_STORE_KV(kcur ^ L::KTILE, vnext_);                                                      \
+        __syncthreads();                                                                            \
+        if (WITH_KF) {                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < PF; ++i_)                                       \
+                kpre[i_] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(                           \
+                    k_rd + (kcur ^ L::KTILE) + 32 * i_));                                           \
+            SFA_FENCE();    /* LDS reads first: the address math of the loads below covers them */   \
+        }                                                                                           \
+        SFA_LOAD_KV((T) + 2);                                                                       \
+        SFA_FENCE();                                                                                \
+    } while (0)
+#define SFA_ADVANCE()                                                                               \
+    do {                                                                                            \
+        kcur ^= L::KTILE;                                                                           \
+        vcur = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;                                        \
+    } while (0)
+
+    // FULL steps: this wave needs tile t+1 as well.
+    int t = 0;
+    for (; t + 1 < ntw; ++t) {
+        const char *kb = k_rd + kcur, *vb = v_rd + vcur;
+        h_block<Tr, D, NQB, PF, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
+                                                   mask_bits(t * kBN), t * kBN, h2, lim, kpre);
+        SFA_STAGE_AND_SYNC(t, true);
+        const char *kbn = k_rd + (kcur ^ L::KTILE);
+        h_block<Tr, D, NQB, PF, 0, 1, true, true>(kbn, vb, kbn, qf, sA, sB, acc, c2, mxB, mxA,
+                                                  mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
+        SFA_ADVANCE();
+    }
+    // TAIL step: this wave's last tile (no next scores to compute).
+    if (t < ntw) {
+        const char *kb = k_rd + kcur, *vb = v_rd + vcur;
+        h_block<Tr, D, NQB, PF, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
+                                                   mask_bits(t * kBN), t * kBN, h2, lim, kpre);
+        SFA_STAGE_AND_SYNC(t, false);
+        h_block<Tr, D, NQB, PF, 0, 1, false, false>(kb, vb, kb, qf, sA, sB, acc, c2, mxB, mxA,
+                                                    mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
+        SFA_ADVANCE();
+        ++t;
+    }
+    // idle steps (causal: tiles beyond this wave's diagonal): keep staging for the other waves.
+    for (; t < nt; ++t) {
+        SFA_STAGE_AND_SYNC(t, false);
+        SFA_ADVANCE();
+    }
+#undef SFA_STAGE_AND_SYNC
+#undef SFA_ADVANCE
+
+    // ---- epilogue: normalise, convert, store O[row][:] (lane holds 4 consecutive d per group) ----
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        const int qrow = wq0 + 32 * q + l31;
+        const float ltot = half_sum(acc.lsum[q]);
+        const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+        if (qrow < p.Sq) {
+            uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (long long)qrow * p.os[2] + 4 * h2;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = Tr::pack2(acc.o[q][d][4 * g + 0] * inv, acc.o[q][d][4 * g + 1] * inv);
+                    w.y = Tr::pack2(acc.o[q][d][4 * g + 2] * inv, acc.o[q][d][4 * g + 3] * inv);
+                    *reinterpret_cast<uint2 *>(op + 32 * d + 8 * g) = w;
+                }
+            }
+            if (p.lse && h2 == 0) {
+                const float lse = ltot > 0.f ? (acc.msc[q] + __log2f(ltot)) * kLn2 : ninf();
+                p.lse[((long long)b * p.Hq + h) * p.Sq + qrow] = lse;
+            }
+        }
+    }
+#undef SFA_LOAD_KV
+#undef SFA_STORE_KV
+#undef SFA_LD1
+#undef SFA_LD1C
+}
+
+template <class Tr, int D, int NQB, int PF>
+int launch_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
+    const size_t lds = Lds<D>::TOTAL;      // K[2] + V[3], padded rows
+    dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads / NQB);
+    static bool attr_set = false;       // idempotent; a race only repeats the call
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v5<Tr, D, true, NQB, PF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v5<Tr, D, false, NQB, PF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (causal) {
+        hipLaunchKernelGGL((prefill_kernel_v5<Tr, D, true, NQB, PF>), grid, block, lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((prefill_kernel_v5<Tr, D, false, NQB, PF>), grid, block, lds, stream, p);
+    }
+    return check_launch("prefill_kernel_v5");
+}
+
+template <int NQB, int PF>
+int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+    if (dtype == SFA_DTYPE_FP16) {
+        if (head_dim == 128) return launch_t<Fp16, 128, NQB, PF>(p, causal, stream);
+        if (head_dim == 64) return launch_t<Fp16, 64, NQB, PF>(p, causal, stream);
+    } else if (dtype == SFA_DTYPE_BF16) {
+        if (head_dim == 128) return launch_t<Bf16, 128, NQB, PF>(p, causal, stream);
+        if (head_dim == 64) return launch_t<Bf16, 64, NQB, PF>(p, causal, stream);
+    } else {
+        return fail(SFA_ERR_BAD_DTYPE, "sfa_prefill_fwd: dtype %d is not fp16(0)/bf16(1)", dtype);
+    }
+    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: head_dim %d not in {64, 128}", head_dim);
+}
+
+}  // namespace
+
+// NQB = 1: 8 waves x 32 rows
+int launch_prefill_v5(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+    return launch_cfg<1, 2>(p, dtype, head_dim, causal, stream);
+}
+// NQB = 2: 4 waves x 64 rows, one wave per SIMD
+int launch_prefill_v6(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+    return launch_cfg<2, 2>(p, dtype, head_dim, causal, stream);
+}
+
+}  // namespace sfa
