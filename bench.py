@@ -155,13 +155,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps          # avg launch duration (back-to-back launches)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    from starflashattention_amd.sharding import aggregate_throughput, max_over_ranks
+    elapsed = max_over_ranks(elapsed, dist, dev)          # the job is as slow as its slowest rank
 
     flops_step = attn_flops(B, H, S, S, D, causal)        # per rank
-    total_tflops = world * flops_step * args.steps / elapsed / 1e12
+    total_tflops = aggregate_throughput(flops_step, args.steps, elapsed, world) / 1e12
     kern_tflops = flops_step / (kernel_ms * 1e-3) / 1e12
 
     if rank == 0:
@@ -178,7 +176,7 @@ def main():
                        "causal": causal, "parallelism": f"batch-shard x{world}"},
             "tflops_per_gpu": round(total_tflops / world, 2),
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal>",
+            "roofline": {"bound": "mfma", "kernel": "prefill_kernel_v5<Bf16,128,causal,NQB=1>",
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},

@@ -122,8 +122,23 @@ def build_pybind(force=False, verbose=False):
     return out
 
 
+def build_examples(force=False, verbose=False):
+    """hipcc the torch-free C++ harness against the C++ surface (src/flash_attn.h)."""
+    lib = build_lib()
+    src = os.path.join(ROOT, "examples", "cpp", "flash_decoder_harness.cc")
+    out = os.path.join(ROOT, "build", "flash_decoder_harness")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if (not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(lib))):
+        return out
+    log = _run([hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-I" + ROOT, src, "-L" + LIBDIR,
+                "-lStarFlashAttention", "-Wl,-rpath,$ORIGIN/../starflashattention_amd/lib", "-o", out])
+    if verbose and log.strip():
+        print(log)
+    return out
+
+
 def build_all(force=False, verbose=False):
-    return build_lib(force, verbose), build_pybind(force, verbose)
+    return build_lib(force, verbose), build_pybind(force, verbose), build_examples(force, verbose)
 
 
 if __name__ == "__main__":
@@ -132,3 +147,4 @@ if __name__ == "__main__":
     print(build_lib(force, verbose=True))
     if not only_lib:
         print(build_pybind(force, verbose=True))
+        print(build_examples(force, verbose=True))

@@ -99,3 +99,49 @@ def test_ops_fail_loudly_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libStarFlashAttention.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_pybind_extension_surface_matches_reference():
+    """Module name, function name and the 16 keyword names in order (reference flash_api.cpp:70-80)."""
+    import glob
+    import importlib
+    if not glob.glob(os.path.join(ROOT, "star_flash_attn*.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    ext = importlib.import_module("star_flash_attn")
+    doc = ext.mha_fwd_cuda.__doc__
+    names = ["qkv", "q_bias", "k_bias", "v_bias", "k_cache_table", "v_cache_table", "seq_len", "o",
+             "batch_size", "memory_max_len", "num_heads", "head_dim", "rotary_embedding_dim",
+             "max_input_length", "num_layer", "idx_layer"]
+    sig = doc.split("\n")[0]
+    got = re.findall(r"(\w+): ", sig)
+    assert got == names, got
+    assert "-> torch.Tensor" in sig
+    import torch
+    with pytest.raises(RuntimeError, match="HIP device"):      # CPU tensors are refused, not computed on
+        z = torch.zeros(1, 3, 2, 128, dtype=torch.float16)
+        ext.mha_fwd_cuda(z, z, z, z, z, z, z, z, 1, 4, 2, 128, 128, 4, 1, 0)
+
+
+def test_params_header_abi():
+    """src/params.h keeps the reference's field order (params.h:10-68): compile a tiny TU that checks
+    the offsets the reference layout implies."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent('''
+        #include <src/params.h>
+        #include <cstddef>
+        static_assert(offsetof(Flash_decoder_input, q_bias) == 8, "");
+        static_assert(offsetof(Flash_decoder_input, v_cache_table) == 56, "");
+        static_assert(offsetof(Flash_decoder_input, rotary_sin_table) == 72, "");
+        static_assert(offsetof(Flash_decoder_input, memory_max_len) == 84, "");
+        static_assert(offsetof(Flash_decoder_input, stride) == 108, "");
+        static_assert(offsetof(Flash_decoder_params, num_splits) == 4, "");
+        static_assert(offsetof(Flash_decoder_buffers, m_formula) == 16, "");
+        int main() { Flash_decoder_input i; return i.qkv == nullptr ? 0 : 1; }
+    ''')
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "abi.cpp")
+        open(f, "w").write(src)
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-fsyntax-only", "-I" + ROOT, "-x", "hip",
+                            "--offload-arch=gfx950", f], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
