@@ -17,7 +17,8 @@
 //   * num_splits is chosen by the library (the reference hard-codes 4);
 //   * additive entry points: mha_fwd (prefill forward), compute_rotary_table, check_errors.
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm tensors say "cuda"
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
 #include <cmath>
@@ -119,13 +120,13 @@ at::Tensor mha_fwd_cuda(at::Tensor &qkv, at::Tensor &q_bias, at::Tensor &k_bias,
     if (opt_ptr(k_bias)) check_tensor(k_bias, "k_bias", st, {H, D}, dev);
     if (opt_ptr(v_bias)) check_tensor(v_bias, "v_bias", st, {H, D}, dev);
 
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     Flash_decoder_input input;
     set_input(input, qkv, q_bias, k_bias, v_bias, o, k_cache_table, v_cache_table, seq_len, batch_size,
               memory_max_len, num_heads, head_dim, rotary_embedding_dim, max_input_length, num_layer, idx_layer);
     Flash_decoder_params params;
     set_default_params(params);
-    hipStream_t stream = at::hip::getCurrentHIPStream(dev.index()).stream();
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
 
     sfa_decode_args a;
     a.qkv = input.qkv;
@@ -161,8 +162,8 @@ at::Tensor mha_fwd_cuda(at::Tensor &qkv, at::Tensor &q_bias, at::Tensor &k_bias,
 // Raise if any earlier mha_fwd_cuda call on the current stream saw seq_len[b] outside
 // [0, memory_max_len).  Synchronises that stream.
 void check_errors() {
-    const int devi = at::hip::current_device();
-    hipStream_t stream = at::hip::getCurrentHIPStream(devi).stream();
+    const int devi = c10::hip::current_device();
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(devi).stream();
     at::Tensor ws;
     {
         std::lock_guard<std::mutex> lock(g_mu);
@@ -194,7 +195,7 @@ std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const 
     at::Tensor lse;
     if (return_lse) lse = at::empty({q.size(0), q.size(1), q.size(2)}, q.options().dtype(at::kFloat));
 
-    c10::hip::HIPGuard guard(q.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
     sfa_prefill_args a;
     a.q = q.data_ptr(); a.k = k.data_ptr(); a.v = v.data_ptr(); a.o = out.data_ptr();
     a.lse = return_lse ? lse.data_ptr<float>() : nullptr;
@@ -207,7 +208,7 @@ std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const 
     a.softmax_scale = (float)softmax_scale;
     a.causal = causal ? 1 : 0;
     a.dtype = dt;
-    check_status(sfa_prefill_fwd(&a, at::hip::getCurrentHIPStream(q.device().index()).stream()), "mha_fwd");
+    check_status(sfa_prefill_fwd(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream()), "mha_fwd");
     if (return_lse) return {out, lse};
     return {out};
 }
@@ -215,9 +216,9 @@ std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const 
 std::vector<at::Tensor> compute_rotary_table(int max_seq_len, int rot_dim, at::ScalarType dtype, at::Device device) {
     at::Tensor c = at::empty({max_seq_len, rot_dim / 2}, at::TensorOptions().dtype(dtype).device(device));
     at::Tensor s = at::empty_like(c);
-    c10::hip::HIPGuard guard(device);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(device);
     check_status(sfa_compute_rotary_table(c.data_ptr(), s.data_ptr(), max_seq_len, rot_dim, dtype_code(c, "table"),
-                                          at::hip::getCurrentHIPStream(device.index()).stream()),
+                                          c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device.index()).stream()),
                  "compute_rotary_table");
     return {c, s};
 }

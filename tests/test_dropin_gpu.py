@@ -104,7 +104,8 @@ def test_extension_prefill_and_rotary_table(ext):
 
 def test_python_example_runs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "python", "decode_dropin.py")],
-                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+                       cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max |star_flash_attn - torch|" in r.stdout
 
