@@ -102,12 +102,17 @@ struct Acc {
 //   mxN[q]    out: this lane's max over the 16 new scores
 //   mask_o    bit q set: sO[q] holds keys that must be masked (diagonal / ragged tiles)
 //   PF        how many slots ahead of its MFMAs a fragment is read
-template <class Tr, int D, int NQB, int PF, int HN, int HO, bool DO_QK, bool PREF>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <class Tr, int D, int NQB, int PF, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook, class PvHook = NoHook>
 __device__ __forceinline__ void h_block(const char *kb, const char *vb, const char *kb_pref,
                                         const typename Tr::mfma_vec (&qf)[NQB][D / 16],
                                         f32x16 (&sN)[NQB], f32x16 (&sO)[NQB], Acc<D, NQB> &acc, float c2,
                                         const float (&mxO)[NQB], float (&mxN)[NQB], int mask_o, int kbase_o,
-                                        int h2, const int (&lim)[NQB], typename Tr::mfma_vec (&kpre)[PF]) {
+                                        int h2, const int (&lim)[NQB], typename Tr::mfma_vec (&kpre)[PF],
+                                        const QkHook &qk_hook = QkHook(), const PvHook &pv_hook = PvHook()) {
+    // qk_hook(i) / pv_hook(j): extra work the caller wants issued inside QK slot i / PV slot j
+    // (staging loads and stores spread under the MFMAs instead of bunched at the barrier)
     using Vec = typename Tr::mfma_vec;
     constexpr int NKS = D / 16, NDB = D / 32, NPV = 2 * NDB;
     constexpr int KS = Lds<D>::KS, VS = Lds<D>::VS;
@@ -188,6 +193,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
             for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[i], qf[q][i], sN[q]);
 #pragma unroll
             for (int e = (i - 1) * 8 / (NKS - 1); e < i * 8 / (NKS - 1); ++e) soft1(e);
+            qk_hook(i);
             SFA_FENCE();
         }
     } else {
@@ -226,6 +232,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
                     m1[q] = max3(m1[q], sN[q][r + 2], sN[q][r + 3]);
                 }
         }
+        pv_hook(j);
         SFA_FENCE();
     }
 #pragma unroll
@@ -274,6 +281,13 @@ prefill_kernel_v5(const PrefillKernelParams p) {
             qf[q][ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
         lim[q] = CAUSAL ? min(p.Sk - 1, qrow + coff) : p.Sk - 1;
     }
+    // Launder the Q fragments through an empty asm: hipcc waits for their global loads HERE and
+    // afterwards no longer ties these registers to the VM counter (its loop-carried scoreboard
+    // otherwise keeps a stale vmcnt(N) in front of every QK^T MFMA).
+#pragma unroll
+    for (int q = 0; q < NQB; ++q)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[q][ks]));
 
     // tiles the workgroup walks / tiles this wave computes on (both wave-uniform)
     int kv_end = p.Sk;
@@ -336,6 +350,32 @@ prefill_kernel_v5(const PrefillKernelParams p) {
             *reinterpret_cast<uint4 *>(v_w + (VBUF) + 3 * ROWSTEP * L::VS) = vr3;                    \
         }                                                                                           \
     } while (0)
+
+    // The same staging, one chunk at a time (op n < 2*NLD: even = K chunk n/2, odd = V chunk n/2), so
+    // the FULL steps can issue the loads inside H2's first QK slots and the ds_writes inside H1's
+    // last PV slots instead of bunching them around the barrier.
+    constexpr int NOPS = 2 * NLD;
+    auto load_op = [&](int n, int kt) {
+        const bool whole = (kt + 1) * kBN <= p.Sk;
+#define SFA_LDOP(N, KR, VR, I)                                                                      \
+        if (n == (N)) { if (whole) SFA_LD1(KR, kg, k_rowb, k_tile_bytes, I, kt); else SFA_LD1C(KR, kg, k_rowb, I, kt); } \
+        if (n == (N) + 1) { if (whole) SFA_LD1(VR, vg, v_rowb, v_tile_bytes, I, kt); else SFA_LD1C(VR, vg, v_rowb, I, kt); }
+        SFA_LDOP(0, kr0, vr0, 0)
+        if (NLD > 1) { SFA_LDOP(2, kr1, vr1, 1) }
+        if (NLD > 2) { SFA_LDOP(4, kr2, vr2, 2) }
+        if (NLD > 3) { SFA_LDOP(6, kr3, vr3, 3) }
+#undef SFA_LDOP
+    };
+    auto store_op = [&](int n, int kbuf, int vbuf) {
+#define SFA_STOP(N, KR, VR, I)                                                                      \
+        if (n == (N)) *reinterpret_cast<uint4 *>(k_w + kbuf + (I) * ROWSTEP * L::KS) = KR;           \
+        if (n == (N) + 1) *reinterpret_cast<uint4 *>(v_w + vbuf + (I) * ROWSTEP * L::VS) = VR;
+        SFA_STOP(0, kr0, vr0, 0)
+        if (NLD > 1) { SFA_STOP(2, kr1, vr1, 1) }
+        if (NLD > 2) { SFA_STOP(4, kr2, vr2, 2) }
+        if (NLD > 3) { SFA_STOP(6, kr3, vr3, 3) }
+#undef SFA_STOP
+    };
 
     Acc<D, NQB> acc;
 #pragma unroll
@@ -423,16 +463,33 @@ prefill_kernel_v5(const PrefillKernelParams p) {
         vcur = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;                                        \
     } while (0)
 
-    // FULL steps: this wave needs tile t+1 as well.
+    // FULL steps: this wave needs tile t+1 as well.  Staging is spread under the MFMAs: the ds_writes
+    // of tile t+1 ride in the last PV slots of H1(t) (its buffers are free during all of H1(t)), the
+    // global loads of tile t+2 in the first QK slots of H2(t).
+    constexpr int NPV_ = 2 * NDB;
     int t = 0;
     for (; t + 1 < ntw; ++t) {
         const char *kb = k_rd + kcur, *vb = v_rd + vcur;
+        const int knext = kcur ^ L::KTILE, vnext = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;
+        auto st_hook = [&](int j) {         // NOPS stores spread evenly over the NPV slots
+#pragma unroll
+            for (int n = j * NOPS / NPV_; n < (j + 1) * NOPS / NPV_; ++n) store_op(n, knext, vnext);
+        };
         h_block<Tr, D, NQB, PF, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
-                                                   mask_bits(t * kBN), t * kBN, h2, lim, kpre);
-        SFA_STAGE_AND_SYNC(t, true);
-        const char *kbn = k_rd + (kcur ^ L::KTILE);
+                                                   mask_bits(t * kBN), t * kBN, h2, lim, kpre, NoHook(), st_hook);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            kpre[i] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + knext + 32 * i));
+        SFA_FENCE();
+        const int tn = t + 2;
+        auto ld_hook = [&](int i) {         // NOPS loads spread evenly over QK slots 1..NKS-1
+#pragma unroll
+            for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, tn);
+        };
+        const char *kbn = k_rd + knext;
         h_block<Tr, D, NQB, PF, 0, 1, true, true>(kbn, vb, kbn, qf, sA, sB, acc, c2, mxB, mxA,
-                                                  mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
+                                                  mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre, ld_hook);
         SFA_ADVANCE();
     }
     // TAIL step: this wave's last tile (no next scores to compute).
