@@ -176,7 +176,7 @@ def main():
                        "causal": causal, "parallelism": f"batch-shard x{world}"},
             "tflops_per_gpu": round(total_tflops / world, 2),
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "prefill_kernel_v5<Bf16,128,causal,NQB=1>",
+            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal,NQB=1,PF=2>",
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},

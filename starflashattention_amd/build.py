@@ -23,8 +23,10 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB_NAME = "libStarFlashAttention.so"
 ARCH = "gfx950"
 
-KERNEL_SOURCES = ["decode_kernel.hip", "prefill_v0.hip", "prefill_v1.hip", "prefill_v2.hip", "prefill_v3.hip", "prefill_v5.hip", "prefill_dispatch.hip", "aux_kernels.hip", "c_api.hip",
-                  "cxx_surface.hip"]
+EXTRA_FLAGS = {}      # per-source extra hipcc flags (none needed at present)
+
+KERNEL_SOURCES = ["decode_kernel.hip", "prefill_kernel.hip", "prefill_baseline.hip", "prefill_dispatch.hip",
+                  "aux_kernels.hip", "c_api.hip", "cxx_surface.hip"]
 
 
 def hipcc():
@@ -65,7 +67,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in KERNEL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + ROOT,
              "-Wall", "-Wno-unused-function"] + list(extra_flags)
-    stamp = _stamp(srcs + _headers(), " ".join(flags))
+    stamp = _stamp(srcs + _headers(), " ".join(flags) + repr(sorted(EXTRA_FLAGS.items())))
     stamp_file = out + ".stamp"
     if (not force and os.path.exists(out) and os.path.exists(stamp_file)
             and open(stamp_file).read() == stamp):
@@ -74,7 +76,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
-        log = _run([cc] + flags + ["-c", src, "-o", obj])
+        log = _run([cc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
         if verbose and log.strip():
             print(log)
         return obj

@@ -1,5 +1,7 @@
-// Fused attention forward (prefill) for gfx950 (MI355X), bf16 / fp16, head_dim 64 / 128,
-// causal or full, MHA or GQA.  The reference has no prefill kernel; this is the new entry
+// BASELINE generation of the prefill kernel (one tile at a time, no software pipeline, XOR-swizzled
+// LDS images): kept in the library only as the in-process A/B reference for tools/prefill_ab.py
+// (SFA_PREFILL_IMPL=0); 538 TFLOPS where the product kernel (prefill_kernel.hip) reaches ~900.
+// bf16 / fp16, head_dim 64 / 128, causal or full, MHA or GQA.  The reference has no prefill kernel; this is the new entry
 // point BASELINE.json's headline metric is quoted on (SURVEY.md section 8(a) row A-new).
 //
 // MI355X design (MFMA-bound: AI = 1024 FLOP/B at S=4096, D=128):
@@ -30,7 +32,7 @@ using namespace prefill;
 
 template <class Tr, int D, bool CAUSAL>
 __global__ void __launch_bounds__(kThreads, 2)
-prefill_kernel_v0(const PrefillKernelParams p) {
+prefill_kernel_baseline(const PrefillKernelParams p) {
     using Vec = typename Tr::mfma_vec;
     constexpr int NKS = D / 16;                 // k-steps of Q.K^T
     constexpr int NDB = D / 32;                 // 32-wide d blocks of O^T
@@ -240,23 +242,23 @@ int launch_prefill_t(const PrefillKernelParams &p, bool causal, hipStream_t stre
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v0<Tr, D, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v0<Tr, D, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (causal) {
-        hipLaunchKernelGGL((prefill_kernel_v0<Tr, D, true>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel_baseline<Tr, D, true>), grid, block, lds, stream, p);
     } else {
-        hipLaunchKernelGGL((prefill_kernel_v0<Tr, D, false>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel_baseline<Tr, D, false>), grid, block, lds, stream, p);
     }
-    return check_launch("prefill_kernel_v0");
+    return check_launch("prefill_kernel_baseline");
 }
 
 }  // namespace
 
-int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_prefill_t<Fp16, 128>(p, causal, stream);
         if (head_dim == 64) return launch_prefill_t<Fp16, 64>(p, causal, stream);

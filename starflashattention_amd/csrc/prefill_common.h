@@ -1,5 +1,5 @@
-// Shared pieces of the gfx950 prefill kernels: tile geometry, the two LDS images and the
-// block -> (head, q-tile) map.  See prefill_v1.hip for the design notes.
+// Shared pieces of the gfx950 prefill kernels: tile geometry, the XOR-swizzled LDS images of the
+// baseline generation and the block -> (head, q-tile) map.  Design notes: prefill_kernel.hip.
 #pragma once
 #include "sfa_device.h"
 #include "sfa_host.h"
@@ -42,15 +42,8 @@ __device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) 
 
 }  // namespace prefill
 
-// one launcher per kernel generation; launch_prefill (prefill_dispatch.hip) picks one
-int launch_prefill_v0(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v1(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v3(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v5(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_v6(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
-int launch_prefill_ablation(const PrefillKernelParams &p, int abl, int dtype, int head_dim, bool causal,
-                            hipStream_t stream);
+// the product kernel and the baseline generation kept for A/B runs; launch_prefill picks one
+int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 
 }  // namespace sfa

@@ -1,15 +1,16 @@
-// Fused attention forward (prefill) for gfx950 (MI355X), generation 5: half-tile software
+// Fused attention forward (prefill) for gfx950 (MI355X), the product kernel: half-tile software
 // pipeline, explicitly slot-ordered, NQB query blocks per wave.
 // bf16 / fp16, head_dim 64 / 128, causal or full, MHA or GQA.  The reference has no prefill
 // kernel; this is the entry point BASELINE.json's headline metric is quoted on (SURVEY.md
 // section 8(a) row A-new).
 //
 // MI355X design (MFMA-bound: AI = 1024 FLOP/B at S=4096, D=128):
-//   * workgroup = 256 query rows of one (batch, head).  NQB = 2: 4 waves, one per SIMD, each
-//     owning 64 rows (two 32-row query blocks) and the whole 512-register file; NQB = 1: 8 waves
-//     of 32 rows at two waves per SIMD.  With NQB = 2 every K / V fragment read from LDS feeds TWO
-//     MFMAs, which halves the LDS operand traffic (1 KB per MFMA at NQB = 1 -- measured to be
-//     what holds that variant at ~55 % MFMA utilisation even with all softmax work removed).
+//   * workgroup = 256 query rows of one (batch, head).  NQB = 1 (shipped): 8 waves of 32 rows, two
+//     waves per SIMD.  NQB = 2 (4 waves x 64 rows, one per SIMD, 512-register file, every K / V
+//     fragment feeding two MFMAs) is kept as a template parameter: it halves the LDS operand
+//     traffic, but as scheduled by hipcc 7.2 it measured 687 vs 868 TFLOPS (needs
+//     -mllvm -amdgpu-mfma-vgpr-form=1 to avoid ~2000 v_accvgpr copies; still 336 of them) -- it
+//     wants hand-placed AGPR ownership, which is a later round's work.
 //   * K/V tiles of 64 keys are staged once per workgroup into LDS (register-staged: global loads
 //     in flight for a whole tile time, then ds_write; K double-, V triple-buffered; ONE barrier
 //     per tile) and shared by all waves.
@@ -244,7 +245,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
 
 template <class Tr, int D, bool CAUSAL, int NQB, int PF>
 __global__ void __launch_bounds__(kThreads / NQB, 2 / NQB)
-prefill_kernel_v5(const PrefillKernelParams p) {
+prefill_kernel(const PrefillKernelParams p) {
     using Vec = typename Tr::mfma_vec;
     constexpr int THREADS = kThreads / NQB;     // 512 (8 waves) or 256 (4 waves)
     constexpr int WROWS = 32 * NQB;             // query rows per wave
@@ -547,18 +548,18 @@ int launch_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads / NQB);
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v5<Tr, D, true, NQB, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true, NQB, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_v5<Tr, D, false, NQB, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false, NQB, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (causal) {
-        hipLaunchKernelGGL((prefill_kernel_v5<Tr, D, true, NQB, PF>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel<Tr, D, true, NQB, PF>), grid, block, lds, stream, p);
     } else {
-        hipLaunchKernelGGL((prefill_kernel_v5<Tr, D, false, NQB, PF>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel<Tr, D, false, NQB, PF>), grid, block, lds, stream, p);
     }
-    return check_launch("prefill_kernel_v5");
+    return check_launch("prefill_kernel");
 }
 
 template <int NQB, int PF>
@@ -577,13 +578,8 @@ int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causa
 
 }  // namespace
 
-// NQB = 1: 8 waves x 32 rows
-int launch_prefill_v5(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    return launch_cfg<1, 2>(p, dtype, head_dim, causal, stream);
-}
-// NQB = 2: 4 waves x 64 rows, one wave per SIMD
-int launch_prefill_v6(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    return launch_cfg<2, 2>(p, dtype, head_dim, causal, stream);
+int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+    return launch_cfg<1, 2>(p, dtype, head_dim, causal, stream);      // NQB = 1, fragment prefetch distance 2
 }
 
 }  // namespace sfa
