@@ -163,6 +163,13 @@ def main():
     kern_tflops = flops_step / (kernel_ms * 1e-3) / 1e12
 
     if rank == 0:
+        traffic, traffic_src = None, None
+        try:                    # committed PMC measurement of this same command (tools/profile_bench.sh)
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                traffic = json.load(f)["prefill_kernel<Bf16, 128, true, 1, 2>"]["total_bytes"]
+                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except Exception:
+            pass
         rec = {
             "metric": "attention fwd TFLOPS/GPU (% MFMA peak), bf16 seqlen=4096 hdim=128",
             "value": round(total_tflops, 2), "unit": "TFLOPS",
@@ -178,7 +185,8 @@ def main():
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal,NQB=1,PF=2>",
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},
         }
         if world == 1 and not args.no_decode:

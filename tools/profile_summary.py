@@ -6,7 +6,8 @@ counts 64 B per 128-B request for wide coalesced reads, so it is doubled here
 import csv, glob, os, sys, collections
 root = sys.argv[1]
 def short(n):
-    return n.split("(")[0].replace("void ", "").replace("sfa::(anonymous namespace)::", "")[:70]
+    n = n.replace("void ", "").replace("sfa::(anonymous namespace)::", "").replace("sfa::", "")
+    return n.split("(")[0][:70]
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel-trace stats (", os.path.relpath(f, root), ")")
     for row in csv.DictReader(open(f)):
