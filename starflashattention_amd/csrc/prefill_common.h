@@ -44,6 +44,8 @@ __device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) 
 
 // the product kernel and the baseline generation kept for A/B runs; launch_prefill picks one
 int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, int head_dim, bool causal,
+                           hipStream_t stream);
 int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 
 }  // namespace sfa

@@ -15,6 +15,7 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // A/B harness only: re-read every call
     const int which = e ? std::atoi(e) : impl;
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
+    if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);
 }
 

@@ -39,6 +39,8 @@
 //     lane-constant base plus a compile-time immediate -- two LDS address registers in total --
 //     and SQ_LDS_BANK_CONFLICT measures 0.
 //   * blockIdx -> (head, q-tile) is XCD-aware (prefill_common.h).
+#include <type_traits>
+
 #include "prefill_common.h"
 
 namespace sfa {
@@ -105,7 +107,7 @@ struct Acc {
 //   PF        how many slots ahead of its MFMAs a fragment is read
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-template <class Tr, int D, int NQB, int PF, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook, class PvHook = NoHook>
+template <class Tr, int D, int NQB, int PF, int ORD, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook, class PvHook = NoHook>
 __device__ __forceinline__ void h_block(const char *kb, const char *vb, const char *kb_pref,
                                         const typename Tr::mfma_vec (&qf)[NQB][D / 16],
                                         f32x16 (&sN)[NQB], f32x16 (&sO)[NQB], Acc<D, NQB> &acc, float c2,
@@ -186,15 +188,60 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
         }
     };
 
+    // ORD == 2: the same work software-pipelined across slots in three stages per element pair --
+    // F (scale+subtract), X (v_exp), A (row sum + pack) -- so no instruction sits right behind
+    // the one it depends on (fma -> exp -> add/cvt back to back stalls on VALU/TRANS latency).
+    // Pair g (elements 2g, 2g+1) does F in soft-slot g, X in g+1, A in g+2; soft-slot u is QK slot
+    // u+1 for u < NKS-1 and PV slot u-(NKS-1) after that.  Needs NKS >= 8 (pairs 0..3 packed before
+    // the first PV MFMA, pairs 4..7 before PV slot NPV/2).
+    constexpr bool STAGED = (ORD == 2) && (NKS >= 8) && DO_QK;
+    auto stage_f = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            sO[q][2 * g] = fmaf(sO[q][2 * g], c2, -msafe[q]);
+            sO[q][2 * g + 1] = fmaf(sO[q][2 * g + 1], c2, -msafe[q]);
+        }
+    };
+    auto stage_x = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            sO[q][2 * g] = fast_exp2(sO[q][2 * g]);
+            sO[q][2 * g + 1] = fast_exp2(sO[q][2 * g + 1]);
+        }
+    };
+    auto stage_a = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            rs0[q] += sO[q][2 * g];
+            rs1[q] += sO[q][2 * g + 1];
+            pk[q][g] = Tr::pack2(sO[q][2 * g], sO[q][2 * g + 1]);
+        }
+    };
+    auto staged_slot = [&](int u) {
+        if (u - 2 >= 0 && u - 2 < 8) stage_a(u - 2);
+        if (u - 1 >= 0 && u - 1 < 8) stage_x(u - 1);
+        if (u < 8) stage_f(u);
+    };
+
     if (DO_QK) {
 #pragma unroll
         for (int i = 1; i < NKS; ++i) {     // elements 0..7 spread over slots 1..NKS-1
             if (i + PF < NKS) kf[i + PF] = ld_k(i + PF); else vf[i + PF - NKS] = ld_v(i + PF - NKS);
+            if (ORD != 1) {
 #pragma unroll
-            for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[i], qf[q][i], sN[q]);
+                for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[i], qf[q][i], sN[q]);
+            }
+            if (STAGED) {
+                staged_slot(i - 1);
+            } else {
 #pragma unroll
-            for (int e = (i - 1) * 8 / (NKS - 1); e < i * 8 / (NKS - 1); ++e) soft1(e);
+                for (int e = (i - 1) * 8 / (NKS - 1); e < i * 8 / (NKS - 1); ++e) soft1(e);
+            }
             qk_hook(i);
+            if (ORD == 1) {     // VALU slice first: it runs while this slot's fragment is still in flight
+#pragma unroll
+                for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[i], qf[q][i], sN[q]);
+            }
             SFA_FENCE();
         }
     } else {
@@ -213,17 +260,23 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
             kpre[j + PF - NPV] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(
                 kb_pref + KS * 32 * (1 - HN) + 32 * (j + PF - NPV)));
         }
+        auto pv_mfma = [&]() {
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            uint4 w;
-            w.x = pk[q][4 * (j / NDB) + 0]; w.y = pk[q][4 * (j / NDB) + 1];
-            w.z = pk[q][4 * (j / NDB) + 2]; w.w = pk[q][4 * (j / NDB) + 3];
-            acc.o[q][j % NDB] = Tr::mfma32(vf[j], bitcast<Vec>(w), acc.o[q][j % NDB]);
-        }
-        if (j < NPV / 2) {
+            for (int q = 0; q < NQB; ++q) {
+                uint4 w;
+                w.x = pk[q][4 * (j / NDB) + 0]; w.y = pk[q][4 * (j / NDB) + 1];
+                w.z = pk[q][4 * (j / NDB) + 2]; w.w = pk[q][4 * (j / NDB) + 3];
+                acc.o[q][j % NDB] = Tr::mfma32(vf[j], bitcast<Vec>(w), acc.o[q][j % NDB]);
+            }
+        };
+        if (ORD != 1) pv_mfma();
+        if (STAGED) {
+            staged_slot(NKS - 1 + j);
+        } else if (j < NPV / 2) {
 #pragma unroll
             for (int e = 0; e < EP; ++e) soft1(8 + EP * j + e);
-        } else if (DO_QK) {
+        }
+        if (j >= NPV / 2 && DO_QK) {
 #pragma unroll
             for (int q = 0; q < NQB; ++q)
 #pragma unroll
@@ -234,6 +287,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
                 }
         }
         pv_hook(j);
+        if (ORD == 1) pv_mfma();
         SFA_FENCE();
     }
 #pragma unroll
@@ -243,7 +297,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     }
 }
 
-template <class Tr, int D, bool CAUSAL, int NQB, int PF>
+template <class Tr, int D, bool CAUSAL, int NQB, int PF, int ORD, int DIAG>
 __global__ void __launch_bounds__(kThreads / NQB, 2 / NQB)
 prefill_kernel(const PrefillKernelParams p) {
     using Vec = typename Tr::mfma_vec;
@@ -265,6 +319,7 @@ prefill_kernel(const PrefillKernelParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
+    if ((DIAG & 1) && wave >= (THREADS / 64) / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half
     const int l31 = lane & 31, h2 = lane >> 5;
     const int q0 = bc.qt * kBM;
     const int wq0 = q0 + WROWS * wave;          // this wave's first query row
@@ -468,17 +523,40 @@ prefill_kernel(const PrefillKernelParams p) {
     // of tile t+1 ride in the last PV slots of H1(t) (its buffers are free during all of H1(t)), the
     // global loads of tile t+2 in the first QK slots of H2(t).
     constexpr int NPV_ = 2 * NDB;
+    // DIAG & 2 (diagnostic build only, never the product): workgroup 0 stamps s_memtime at four
+    // points of steps 8..15 into p.lse (as u64[wave][step][4]); the stamp drains lgkmcnt, so read
+    // SHARES from it, not absolute speed (cdna_hip_programming.md section 7, In-kernel stamps).
+    auto stamp = [&](int step, int which) {
+        if ((DIAG & 2) && blockIdx.x == 8 && step >= 8 && step < 16 && p.lse) {
+            unsigned long long tm;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+            if (lane == 0)
+                reinterpret_cast<unsigned long long *>(p.lse)[(wave * 8 + (step - 8)) * 4 + which] = tm;
+        }
+    };
     int t = 0;
+    const bool young = wave >= (THREADS / 64) / 2;      // wave-uniform (readfirstlane above)
+    // The FULL loop exists in two slot orders; with DIAG & 8 the younger half of the workgroup runs
+    // the other order (VALU slice before the MFMA instead of after), so the two waves that share a
+    // SIMD -- which leave every barrier in lockstep -- want the matrix pipe and the VALU port at
+    // different moments of a slot.
+    auto full_steps = [&](auto ord_tag) {
+    constexpr int ORD_ = decltype(ord_tag)::value;
     for (; t + 1 < ntw; ++t) {
+        stamp(t, 0);
+        if (DIAG & 4) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         const char *kb = k_rd + kcur, *vb = v_rd + vcur;
         const int knext = kcur ^ L::KTILE, vnext = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;
         auto st_hook = [&](int j) {         // NOPS stores spread evenly over the NPV slots
 #pragma unroll
             for (int n = j * NOPS / NPV_; n < (j + 1) * NOPS / NPV_; ++n) store_op(n, knext, vnext);
         };
-        h_block<Tr, D, NQB, PF, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
+        h_block<Tr, D, NQB, PF, ORD_, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
                                                    mask_bits(t * kBN), t * kBN, h2, lim, kpre, NoHook(), st_hook);
+        stamp(t, 1);
         __syncthreads();
+        stamp(t, 2);
+        if (DIAG & 4) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             kpre[i] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + knext + 32 * i));
@@ -489,17 +567,21 @@ prefill_kernel(const PrefillKernelParams p) {
             for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, tn);
         };
         const char *kbn = k_rd + knext;
-        h_block<Tr, D, NQB, PF, 0, 1, true, true>(kbn, vb, kbn, qf, sA, sB, acc, c2, mxB, mxA,
+        h_block<Tr, D, NQB, PF, ORD_, 0, 1, true, true>(kbn, vb, kbn, qf, sA, sB, acc, c2, mxB, mxA,
                                                   mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre, ld_hook);
+        stamp(t, 3);
         SFA_ADVANCE();
     }
+    };
+    if ((DIAG & 8) && young) full_steps(std::integral_constant<int, ORD == 0 ? 1 : 0>());
+    else full_steps(std::integral_constant<int, ORD>());
     // TAIL step: this wave's last tile (no next scores to compute).
     if (t < ntw) {
         const char *kb = k_rd + kcur, *vb = v_rd + vcur;
-        h_block<Tr, D, NQB, PF, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
+        h_block<Tr, D, NQB, PF, ORD, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
                                                    mask_bits(t * kBN), t * kBN, h2, lim, kpre);
         SFA_STAGE_AND_SYNC(t, false);
-        h_block<Tr, D, NQB, PF, 0, 1, false, false>(kb, vb, kb, qf, sA, sB, acc, c2, mxB, mxA,
+        h_block<Tr, D, NQB, PF, ORD, 0, 1, false, false>(kb, vb, kb, qf, sA, sB, acc, c2, mxB, mxA,
                                                     mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
         SFA_ADVANCE();
         ++t;
@@ -530,7 +612,7 @@ prefill_kernel(const PrefillKernelParams p) {
                     *reinterpret_cast<uint2 *>(op + 32 * d + 8 * g) = w;
                 }
             }
-            if (p.lse && h2 == 0) {
+            if (!(DIAG & 2) && p.lse && h2 == 0) {
                 const float lse = ltot > 0.f ? (acc.msc[q] + __log2f(ltot)) * kLn2 : ninf();
                 p.lse[((long long)b * p.Hq + h) * p.Sq + qrow] = lse;
             }
@@ -542,34 +624,34 @@ prefill_kernel(const PrefillKernelParams p) {
 #undef SFA_LD1C
 }
 
-template <class Tr, int D, int NQB, int PF>
+template <class Tr, int D, int NQB, int PF, int ORD, int DIAG>
 int launch_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     const size_t lds = Lds<D>::TOTAL;      // K[2] + V[3], padded rows
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads / NQB);
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true, NQB, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true, NQB, PF, ORD, DIAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false, NQB, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false, NQB, PF, ORD, DIAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (causal) {
-        hipLaunchKernelGGL((prefill_kernel<Tr, D, true, NQB, PF>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel<Tr, D, true, NQB, PF, ORD, DIAG>), grid, block, lds, stream, p);
     } else {
-        hipLaunchKernelGGL((prefill_kernel<Tr, D, false, NQB, PF>), grid, block, lds, stream, p);
+        hipLaunchKernelGGL((prefill_kernel<Tr, D, false, NQB, PF, ORD, DIAG>), grid, block, lds, stream, p);
     }
     return check_launch("prefill_kernel");
 }
 
-template <int NQB, int PF>
+template <int NQB, int PF, int ORD, int DIAG>
 int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
-        if (head_dim == 128) return launch_t<Fp16, 128, NQB, PF>(p, causal, stream);
-        if (head_dim == 64) return launch_t<Fp16, 64, NQB, PF>(p, causal, stream);
+        if (head_dim == 128) return launch_t<Fp16, 128, NQB, PF, ORD, DIAG>(p, causal, stream);
+        if (head_dim == 64) return launch_t<Fp16, 64, NQB, PF, ORD, DIAG>(p, causal, stream);
     } else if (dtype == SFA_DTYPE_BF16) {
-        if (head_dim == 128) return launch_t<Bf16, 128, NQB, PF>(p, causal, stream);
-        if (head_dim == 64) return launch_t<Bf16, 64, NQB, PF>(p, causal, stream);
+        if (head_dim == 128) return launch_t<Bf16, 128, NQB, PF, ORD, DIAG>(p, causal, stream);
+        if (head_dim == 64) return launch_t<Bf16, 64, NQB, PF, ORD, DIAG>(p, causal, stream);
     } else {
         return fail(SFA_ERR_BAD_DTYPE, "sfa_prefill_fwd: dtype %d is not fp16(0)/bf16(1)", dtype);
     }
@@ -579,7 +661,21 @@ int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causa
 }  // namespace
 
 int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    return launch_cfg<1, 2>(p, dtype, head_dim, causal, stream);      // NQB = 1, fragment prefetch distance 2
+    return launch_cfg<1, 2, 0, 0>(p, dtype, head_dim, causal, stream);      // NQB = 1, fragment prefetch distance 2
+}
+// experimental variants for tools/prefill_ab.py (SFA_PREFILL_IMPL = 2, 3, 4)
+int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, int head_dim, bool causal,
+                           hipStream_t stream) {
+    if (which == 2) return launch_cfg<1, 2, 1, 0>(p, dtype, head_dim, causal, stream);
+    if (which == 5) return launch_cfg<1, 2, 0, 2>(p, dtype, head_dim, causal, stream);     // stamps -> lse
+    if (which == 10) return launch_cfg<1, 2, 2, 0>(p, dtype, head_dim, causal, stream);    // staged softmax
+    if (which == 11) return launch_cfg<1, 2, 2, 2>(p, dtype, head_dim, causal, stream);    // staged softmax + stamps
+    if (which == 8) return launch_cfg<1, 2, 0, 8>(p, dtype, head_dim, causal, stream);     // mixed slot order
+    if (which == 9) return launch_cfg<1, 2, 0, 10>(p, dtype, head_dim, causal, stream);    // mixed order + stamps
+    if (which == 6) return launch_cfg<1, 2, 0, 4>(p, dtype, head_dim, causal, stream);     // alternating priority
+    if (which == 7) return launch_cfg<1, 2, 0, 6>(p, dtype, head_dim, causal, stream);     // alternating priority + stamps
+    if (which == 3) return launch_cfg<1, 2, 0, 1>(p, dtype, head_dim, causal, stream);
+    return launch_cfg<1, 2, 1, 1>(p, dtype, head_dim, causal, stream);
 }
 
 }  // namespace sfa
