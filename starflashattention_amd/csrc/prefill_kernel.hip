@@ -11,9 +11,11 @@
 //     traffic, but as scheduled by hipcc 7.2 it measured 687 vs 868 TFLOPS (needs
 //     -mllvm -amdgpu-mfma-vgpr-form=1 to avoid ~2000 v_accvgpr copies; still 336 of them) -- it
 //     wants hand-placed AGPR ownership, which is a later round's work.
-//   * K/V tiles of 64 keys are staged once per workgroup into LDS (register-staged: global loads
-//     in flight for a whole tile time, then ds_write; K double-, V triple-buffered; ONE barrier
-//     per tile) and shared by all waves.
+//   * K/V tiles of 64 keys are staged once per workgroup into LDS and shared by all waves
+//     (register-staged: global loads in flight for a whole tile time, then ds_write; K and V
+//     triple-buffered, K running two tiles ahead of the compute and V one; ONE barrier per tile, and
+//     nothing right behind that barrier depends on what it publishes).  The loads and ds_writes
+//     ride inside the MFMA slots of the half-steps instead of bunching up around the barrier.
 //   * S^T = K . Q^T with v_mfma_f32_32x32x16 (A = K rows from LDS by ds_read_b128, B = Q^T held
 //     in registers for the whole kernel): the 32x32 accumulator has the QUERY on the lane and
 //     keys in registers, so the online-softmax row max / row sum are in-lane loops plus one
@@ -31,6 +33,9 @@
 //     it feeds, the fragment read PF slots ahead, and a slice of the softmax VALU work -- fenced
 //     with sched_barrier(0) so hipcc keeps that order (its own clustering hoisted 50+ fragment
 //     registers, spilled, and a spill reload's vmcnt(0) drained the in-flight staging loads).
+//     The softmax slices are themselves staged across slots (scale/subtract, v_exp, sum+pack of a
+//     pair sit in three consecutive slots) so no VALU instruction issues right behind the one it
+//     depends on (+3 %).
 //   * Lazy rescale: O and the row sum are rescaled only when some row max in the wave grew by
 //     more than 2^8 over the reference max (wave-uniform branch, almost never taken after the
 //     first tiles).  exp2 arguments stay <= 8, so P <= 256: bf16/fp16 keep the same RELATIVE
@@ -61,9 +66,9 @@ template <int D> struct Lds {
     static constexpr int VS = 2 * D + 64;           // V row stride
     static constexpr int KTILE = kBN * KS;
     static constexpr int VTILE = kBN * VS;
-    static constexpr int V_BASE = 2 * KTILE;        // K[2] then V[3]
-    static constexpr int TOTAL = 2 * KTILE + 3 * VTILE;
-    static_assert(3 * VTILE < 65536 && 2 * KTILE < 65536, "ds immediates are 16 bit");
+    static constexpr int V_BASE = 3 * KTILE;        // K[3] then V[3]
+    static constexpr int TOTAL = 3 * KTILE + 3 * VTILE;
+    static_assert(3 * VTILE < 65536 && 3 * KTILE < 65536, "ds immediates are 16 bit");
 };
 
 // key of register r = kbase + (r&3) + 8*(r>>2) + 4*h2
@@ -194,7 +199,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     // Pair g (elements 2g, 2g+1) does F in soft-slot g, X in g+1, A in g+2; soft-slot u is QK slot
     // u+1 for u < NKS-1 and PV slot u-(NKS-1) after that.  Needs NKS >= 8 (pairs 0..3 packed before
     // the first PV MFMA, pairs 4..7 before PV slot NPV/2).
-    constexpr bool STAGED = (ORD == 2) && (NKS >= 8) && DO_QK;
+    constexpr bool STAGED = (ORD == 2) && (NKS >= 8) && DO_QK;     // ORD: 0 = plain slices, 2 = staged, 1 = VALU before MFMA (A/B: no gain)
     auto stage_f = [&](int g) {
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -319,7 +324,6 @@ prefill_kernel(const PrefillKernelParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
-    if ((DIAG & 1) && wave >= (THREADS / 64) / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half
     const int l31 = lane & 31, h2 = lane >> 5;
     const int q0 = bc.qt * kBM;
     const int wq0 = q0 + WROWS * wave;          // this wave's first query row
@@ -337,14 +341,6 @@ prefill_kernel(const PrefillKernelParams p) {
             qf[q][ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
         lim[q] = CAUSAL ? min(p.Sk - 1, qrow + coff) : p.Sk - 1;
     }
-    // Launder the Q fragments through an empty asm: hipcc waits for their global loads HERE and
-    // afterwards no longer ties these registers to the VM counter (its loop-carried scoreboard
-    // otherwise keeps a stale vmcnt(N) in front of every QK^T MFMA).
-#pragma unroll
-    for (int q = 0; q < NQB; ++q)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[q][ks]));
-
     // tiles the workgroup walks / tiles this wave computes on (both wave-uniform)
     int kv_end = p.Sk;
     if (CAUSAL) kv_end = min(p.Sk, q0 + kBM + coff);
@@ -372,50 +368,42 @@ prefill_kernel(const PrefillKernelParams p) {
 #define SFA_LD1C(DST, G, ROWB, I, KT)                                                               \
     DST = *reinterpret_cast<const uint4 *>(                                                         \
         (G) + (long long)min((KT) * kBN + st_row + (I) * ROWSTEP, p.Sk - 1) * (ROWB) + 16u * st_ch)
-#define SFA_LOAD_KV(KT)                                                                             \
+#define SFA_LOAD_ONE(KR0, KR1, KR2, KR3, G, ROWB, TB, KT)                                            \
     do {                                                                                            \
         const int kt_ = (KT);                                                                       \
         if ((kt_ + 1) * kBN <= p.Sk) {                                                              \
-            SFA_LD1(kr0, kg, k_rowb, k_tile_bytes, 0, kt_);                                         \
-            SFA_LD1(vr0, vg, v_rowb, v_tile_bytes, 0, kt_);                                         \
-            if (NLD > 1) { SFA_LD1(kr1, kg, k_rowb, k_tile_bytes, 1, kt_); SFA_LD1(vr1, vg, v_rowb, v_tile_bytes, 1, kt_); } \
-            if (NLD > 2) { SFA_LD1(kr2, kg, k_rowb, k_tile_bytes, 2, kt_); SFA_LD1(vr2, vg, v_rowb, v_tile_bytes, 2, kt_); } \
-            if (NLD > 3) { SFA_LD1(kr3, kg, k_rowb, k_tile_bytes, 3, kt_); SFA_LD1(vr3, vg, v_rowb, v_tile_bytes, 3, kt_); } \
+            SFA_LD1(KR0, G, ROWB, TB, 0, kt_);                                                      \
+            if (NLD > 1) SFA_LD1(KR1, G, ROWB, TB, 1, kt_);                                         \
+            if (NLD > 2) SFA_LD1(KR2, G, ROWB, TB, 2, kt_);                                         \
+            if (NLD > 3) SFA_LD1(KR3, G, ROWB, TB, 3, kt_);                                         \
         } else {                                                                                    \
-            SFA_LD1C(kr0, kg, k_rowb, 0, kt_);                                                      \
-            SFA_LD1C(vr0, vg, v_rowb, 0, kt_);                                                      \
-            if (NLD > 1) { SFA_LD1C(kr1, kg, k_rowb, 1, kt_); SFA_LD1C(vr1, vg, v_rowb, 1, kt_); }  \
-            if (NLD > 2) { SFA_LD1C(kr2, kg, k_rowb, 2, kt_); SFA_LD1C(vr2, vg, v_rowb, 2, kt_); }  \
-            if (NLD > 3) { SFA_LD1C(kr3, kg, k_rowb, 3, kt_); SFA_LD1C(vr3, vg, v_rowb, 3, kt_); }  \
+            SFA_LD1C(KR0, G, ROWB, 0, kt_);                                                         \
+            if (NLD > 1) SFA_LD1C(KR1, G, ROWB, 1, kt_);                                            \
+            if (NLD > 2) SFA_LD1C(KR2, G, ROWB, 2, kt_);                                            \
+            if (NLD > 3) SFA_LD1C(KR3, G, ROWB, 3, kt_);                                            \
         }                                                                                           \
     } while (0)
-#define SFA_STORE_KV(KBUF, VBUF)                                                                    \
+#define SFA_LOAD_K(KT) SFA_LOAD_ONE(kr0, kr1, kr2, kr3, kg, k_rowb, k_tile_bytes, KT)
+#define SFA_LOAD_V(KT) SFA_LOAD_ONE(vr0, vr1, vr2, vr3, vg, v_rowb, v_tile_bytes, KT)
+#define SFA_STORE_ONE(W, RS, BUF, R0, R1, R2, R3)                                                   \
     do {                                                                                            \
-        *reinterpret_cast<uint4 *>(k_w + (KBUF)) = kr0;         /* KBUF/VBUF: byte offsets */       \
-        *reinterpret_cast<uint4 *>(v_w + (VBUF)) = vr0;                                             \
-        if (NLD > 1) {                                                                              \
-            *reinterpret_cast<uint4 *>(k_w + (KBUF) + ROWSTEP * L::KS) = kr1;                        \
-            *reinterpret_cast<uint4 *>(v_w + (VBUF) + ROWSTEP * L::VS) = vr1;                        \
-        }                                                                                           \
-        if (NLD > 2) {                                                                              \
-            *reinterpret_cast<uint4 *>(k_w + (KBUF) + 2 * ROWSTEP * L::KS) = kr2;                    \
-            *reinterpret_cast<uint4 *>(v_w + (VBUF) + 2 * ROWSTEP * L::VS) = vr2;                    \
-        }                                                                                           \
-        if (NLD > 3) {                                                                              \
-            *reinterpret_cast<uint4 *>(k_w + (KBUF) + 3 * ROWSTEP * L::KS) = kr3;                    \
-            *reinterpret_cast<uint4 *>(v_w + (VBUF) + 3 * ROWSTEP * L::VS) = vr3;                    \
-        }                                                                                           \
+        *reinterpret_cast<uint4 *>((W) + (BUF)) = R0;           /* BUF: byte offset */              \
+        if (NLD > 1) *reinterpret_cast<uint4 *>((W) + (BUF) + ROWSTEP * (RS)) = R1;                  \
+        if (NLD > 2) *reinterpret_cast<uint4 *>((W) + (BUF) + 2 * ROWSTEP * (RS)) = R2;              \
+        if (NLD > 3) *reinterpret_cast<uint4 *>((W) + (BUF) + 3 * ROWSTEP * (RS)) = R3;              \
     } while (0)
+#define SFA_STORE_K(KBUF) SFA_STORE_ONE(k_w, L::KS, KBUF, kr0, kr1, kr2, kr3)
+#define SFA_STORE_V(VBUF) SFA_STORE_ONE(v_w, L::VS, VBUF, vr0, vr1, vr2, vr3)
 
     // The same staging, one chunk at a time (op n < 2*NLD: even = K chunk n/2, odd = V chunk n/2), so
     // the FULL steps can issue the loads inside H2's first QK slots and the ds_writes inside H1's
-    // last PV slots instead of bunching them around the barrier.
+    // PV slots instead of bunching them around the barrier.  load_op is the whole-tile fast path
+    // only (uniform tile base + lane offset, no clamping); ragged tiles take SFA_LOAD_K / _V.
     constexpr int NOPS = 2 * NLD;
-    auto load_op = [&](int n, int kt) {
-        const bool whole = (kt + 1) * kBN <= p.Sk;
+    auto load_op = [&](int n, int kt_k, int kt_v) {
 #define SFA_LDOP(N, KR, VR, I)                                                                      \
-        if (n == (N)) { if (whole) SFA_LD1(KR, kg, k_rowb, k_tile_bytes, I, kt); else SFA_LD1C(KR, kg, k_rowb, I, kt); } \
-        if (n == (N) + 1) { if (whole) SFA_LD1(VR, vg, v_rowb, v_tile_bytes, I, kt); else SFA_LD1C(VR, vg, v_rowb, I, kt); }
+        if (n == (N)) SFA_LD1(KR, kg, k_rowb, k_tile_bytes, I, kt_k);                               \
+        if (n == (N) + 1) SFA_LD1(VR, vg, v_rowb, v_tile_bytes, I, kt_v);
         SFA_LDOP(0, kr0, vr0, 0)
         if (NLD > 1) { SFA_LDOP(2, kr1, vr1, 1) }
         if (NLD > 2) { SFA_LDOP(4, kr2, vr2, 2) }
@@ -468,12 +456,38 @@ prefill_kernel(const PrefillKernelParams p) {
         mxA[q] = ninf();
         mxB[q] = ninf();
     }
+    // K runs TWO tiles ahead of the compute, V one: tile t lives in K buffer t % 3 and V buffer
+    // t % 3.  Step t stores K(t+2) and V(t+1) (inside H1's PV slots), syncs once, and loads K(t+3)
+    // and V(t+2) from global memory (inside H2's QK slots).  Because K(t+1) has been visible since
+    // barrier(t-1), the first K fragments of H2(t) are read during the last slots of H1(t): nothing
+    // right behind the barrier depends on what it publishes.
+    // Buffer safety with ONE barrier per tile: K(t+2) overwrites K(t-1), last read in H1(t-1), and
+    // V(t+1) overwrites V(t-2), last read in H2(t-2) -- both before barrier(t-1).  Loads/stores of
+    // tiles past the end are row-clamped and land in buffers nobody reads again.
+    // All prologue loads (Q, K(0), V(0), K(1)) are in flight together before anything waits.
+    uint4 kx0, kx1, kx2, kx3;                   // K(1), prologue only
+    kx0 = kx1 = kx2 = kx3 = make_uint4(0, 0, 0, 0);
     if (nt > 0) {
-        SFA_LOAD_KV(0);
-        SFA_STORE_KV(0, 0);
+        SFA_LOAD_K(0);
+        SFA_LOAD_V(0);
+        SFA_LOAD_ONE(kx0, kx1, kx2, kx3, kg, k_rowb, k_tile_bytes, 1);
+    }
+    // Launder the Q fragments through an empty asm: hipcc waits for their global loads HERE and
+    // afterwards no longer ties these registers to the VM counter (its loop-carried scoreboard
+    // otherwise keeps a stale vmcnt(N) in front of every QK^T MFMA).
+#pragma unroll
+    for (int q = 0; q < NQB; ++q)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[q][ks]));
+
+    if (nt > 0) {
+        SFA_STORE_K(0);
+        SFA_STORE_V(0);
+        SFA_STORE_ONE(k_w, L::KS, L::KTILE, kx0, kx1, kx2, kx3);
     }
     __syncthreads();
-    SFA_LOAD_KV(1);
+    SFA_LOAD_K(2);
+    SFA_LOAD_V(1);
     Vec kpre[PF];                               // first PF K fragments of the next half-step
 #pragma unroll
     for (int i = 0; i < PF; ++i) kpre[i] = bitcast<Vec>(make_uint4(0, 0, 0, 0));
@@ -491,39 +505,29 @@ prefill_kernel(const PrefillKernelParams p) {
         for (int q = 0; q < NQB; ++q) mxA[q] = lane_rowmax(sA[q]);
     }
 
-    // Tile t lives in K buffer t % 2 and V buffer t % 3 (offsets kept as scalars, added to the two
-    // lane bases once per step).  Buffer safety with ONE barrier per tile: K(t+1) overwrites
-    // K(t-1), last read in H1(t-1), i.e. before barrier(t-1); V(t+1) overwrites V(t-2), last
-    // read in H2(t-2), i.e. before barrier(t-1) as well.  Loads/stores of tiles past the end are
-    // row-clamped and land in buffers nobody reads again.
-    int kcur = 0, vcur = 0;         // byte offsets of tile t's buffers
-    // Stage tile t+1 (loaded one step ago), sync, read the first K fragments of H2, put tile t+2
-    // in flight.
-#define SFA_STAGE_AND_SYNC(T, WITH_KF)                                                              \
+    int kcur = 0, vcur = 0;         // byte offsets of tile t's K and V buffers
+#define SFA_NEXT3(X, TILE) (((X) == 2 * (TILE)) ? 0 : (X) + (TILE))
+    // non-overlapped form of the staging (TAIL and idle steps): store, sync, load
+#define SFA_STAGE_AND_SYNC(T)                                                                       \
     do {                                                                                            \
-        const int vnext_ = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;                            \
-        SFA_STORE_KV(kcur ^ L::KTILE, vnext_);                                                      \
+        const int k1_ = SFA_NEXT3(kcur, L::KTILE);                                                  \
+        SFA_STORE_K(SFA_NEXT3(k1_, L::KTILE));                                                      \
+        SFA_STORE_V(SFA_NEXT3(vcur, L::VTILE));                                                     \
         __syncthreads();                                                                            \
-        if (WITH_KF) {                                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < PF; ++i_)                                       \
-                kpre[i_] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(                           \
-                    k_rd + (kcur ^ L::KTILE) + 32 * i_));                                           \
-            SFA_FENCE();    /* LDS reads first: the address math of the loads below covers them */   \
-        }                                                                                           \
-        SFA_LOAD_KV((T) + 2);                                                                       \
+        SFA_LOAD_K((T) + 3);                                                                        \
+        SFA_LOAD_V((T) + 2);                                                                        \
         SFA_FENCE();                                                                                \
     } while (0)
 #define SFA_ADVANCE()                                                                               \
     do {                                                                                            \
-        kcur ^= L::KTILE;                                                                           \
-        vcur = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;                                        \
+        kcur = SFA_NEXT3(kcur, L::KTILE);                                                           \
+        vcur = SFA_NEXT3(vcur, L::VTILE);                                                           \
     } while (0)
 
     // FULL steps: this wave needs tile t+1 as well.  Staging is spread under the MFMAs: the ds_writes
-    // of tile t+1 ride in the last PV slots of H1(t) (its buffers are free during all of H1(t)), the
-    // global loads of tile t+2 in the first QK slots of H2(t).
+    // ride in the PV slots of H1(t), the global loads in the QK slots of H2(t).
     constexpr int NPV_ = 2 * NDB;
-    // DIAG & 2 (diagnostic build only, never the product): workgroup 0 stamps s_memtime at four
+    // DIAG & 2 (diagnostic build only, never the product): one workgroup stamps s_memtime at four
     // points of steps 8..15 into p.lse (as u64[wave][step][4]); the stamp drains lgkmcnt, so read
     // SHARES from it, not absolute speed (cdna_hip_programming.md section 7, In-kernel stamps).
     auto stamp = [&](int step, int which) {
@@ -535,52 +539,54 @@ prefill_kernel(const PrefillKernelParams p) {
         }
     };
     int t = 0;
-    const bool young = wave >= (THREADS / 64) / 2;      // wave-uniform (readfirstlane above)
-    // The FULL loop exists in two slot orders; with DIAG & 8 the younger half of the workgroup runs
-    // the other order (VALU slice before the MFMA instead of after), so the two waves that share a
-    // SIMD -- which leave every barrier in lockstep -- want the matrix pipe and the VALU port at
-    // different moments of a slot.
-    auto full_steps = [&](auto ord_tag) {
-    constexpr int ORD_ = decltype(ord_tag)::value;
-    for (; t + 1 < ntw; ++t) {
+    // H1(t): QK^T(B_t) || exp(A_t), PV(A_t); prefetches the first fragments of K(t+1)'s A half
+#define SFA_H1_FULL()                                                                               \
+    const int k1 = SFA_NEXT3(kcur, L::KTILE), k2 = SFA_NEXT3(k1, L::KTILE);                         \
+    const int v1 = SFA_NEXT3(vcur, L::VTILE);                                                       \
+    const char *kb = k_rd + kcur, *vb = v_rd + vcur, *kb1 = k_rd + k1;                              \
+    auto st_hook = [&](int j) {         /* NOPS stores spread evenly over the NPV slots */           \
+        _Pragma("unroll")                                                                           \
+        for (int n = j * NOPS / NPV_; n < (j + 1) * NOPS / NPV_; ++n) store_op(n, k2, v1);          \
+    };                                                                                              \
+    h_block<Tr, D, NQB, PF, ORD, 1, 0, true, true>(kb, vb, kb1, qf, sB, sA, acc, c2, mxA, mxB,      \
+                                              mask_bits(t * kBN), t * kBN, h2, lim, kpre, NoHook(), st_hook)
+    // steady state: K(t+3) and V(t+2) are whole tiles, their loads ride in H2's QK slots
+    const int t_fast_end = (DIAG & 32) ? 0 : min(ntw - 1, p.Sk / kBN - 3);    // DIAG & 32: loads never ride in slots
+    for (; t < t_fast_end; ++t) {
         stamp(t, 0);
-        if (DIAG & 4) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        const char *kb = k_rd + kcur, *vb = v_rd + vcur;
-        const int knext = kcur ^ L::KTILE, vnext = (vcur == 2 * L::VTILE) ? 0 : vcur + L::VTILE;
-        auto st_hook = [&](int j) {         // NOPS stores spread evenly over the NPV slots
-#pragma unroll
-            for (int n = j * NOPS / NPV_; n < (j + 1) * NOPS / NPV_; ++n) store_op(n, knext, vnext);
-        };
-        h_block<Tr, D, NQB, PF, ORD_, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
-                                                   mask_bits(t * kBN), t * kBN, h2, lim, kpre, NoHook(), st_hook);
+        SFA_H1_FULL();
         stamp(t, 1);
         __syncthreads();
         stamp(t, 2);
-        if (DIAG & 4) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#pragma unroll
-        for (int i = 0; i < PF; ++i)
-            kpre[i] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + knext + 32 * i));
-        SFA_FENCE();
-        const int tn = t + 2;
+        const int tk = t + 3, tv = t + 2;
         auto ld_hook = [&](int i) {         // NOPS loads spread evenly over QK slots 1..NKS-1
 #pragma unroll
-            for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, tn);
+            for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, tk, tv);
         };
-        const char *kbn = k_rd + knext;
-        h_block<Tr, D, NQB, PF, ORD_, 0, 1, true, true>(kbn, vb, kbn, qf, sA, sB, acc, c2, mxB, mxA,
+        // H2(t): QK^T(A_{t+1}) || exp(B_t), PV(B_t); prefetches K(t+1)'s B half for H1(t+1)
+        h_block<Tr, D, NQB, PF, ORD, 0, 1, true, true>(kb1, vb, kb1, qf, sA, sB, acc, c2, mxB, mxA,
                                                   mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre, ld_hook);
         stamp(t, 3);
         SFA_ADVANCE();
     }
-    };
-    if ((DIAG & 8) && young) full_steps(std::integral_constant<int, ORD == 0 ? 1 : 0>());
-    else full_steps(std::integral_constant<int, ORD>());
+    // last FULL steps: the tiles to load are ragged or past the end -> clamped loads up front
+    for (; t + 1 < ntw; ++t) {
+        SFA_H1_FULL();
+        __syncthreads();
+        SFA_LOAD_K(t + 3);
+        SFA_LOAD_V(t + 2);
+        SFA_FENCE();
+        h_block<Tr, D, NQB, PF, ORD, 0, 1, true, true>(kb1, vb, kb1, qf, sA, sB, acc, c2, mxB, mxA,
+                                                  mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
+        SFA_ADVANCE();
+    }
+#undef SFA_H1_FULL
     // TAIL step: this wave's last tile (no next scores to compute).
     if (t < ntw) {
         const char *kb = k_rd + kcur, *vb = v_rd + vcur;
         h_block<Tr, D, NQB, PF, ORD, 1, 0, true, false>(kb, vb, kb, qf, sB, sA, acc, c2, mxA, mxB,
                                                    mask_bits(t * kBN), t * kBN, h2, lim, kpre);
-        SFA_STAGE_AND_SYNC(t, false);
+        SFA_STAGE_AND_SYNC(t);
         h_block<Tr, D, NQB, PF, ORD, 0, 1, false, false>(kb, vb, kb, qf, sA, sB, acc, c2, mxB, mxA,
                                                     mask_bits(t * kBN + 32), t * kBN + 32, h2, lim, kpre);
         SFA_ADVANCE();
@@ -588,9 +594,10 @@ prefill_kernel(const PrefillKernelParams p) {
     }
     // idle steps (causal: tiles beyond this wave's diagonal): keep staging for the other waves.
     for (; t < nt; ++t) {
-        SFA_STAGE_AND_SYNC(t, false);
+        SFA_STAGE_AND_SYNC(t);
         SFA_ADVANCE();
     }
+#undef SFA_NEXT3
 #undef SFA_STAGE_AND_SYNC
 #undef SFA_ADVANCE
 
@@ -618,15 +625,19 @@ prefill_kernel(const PrefillKernelParams p) {
             }
         }
     }
-#undef SFA_LOAD_KV
-#undef SFA_STORE_KV
+#undef SFA_LOAD_K
+#undef SFA_LOAD_V
+#undef SFA_LOAD_ONE
+#undef SFA_STORE_K
+#undef SFA_STORE_V
+#undef SFA_STORE_ONE
 #undef SFA_LD1
 #undef SFA_LD1C
 }
 
 template <class Tr, int D, int NQB, int PF, int ORD, int DIAG>
 int launch_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
-    const size_t lds = Lds<D>::TOTAL;      // K[2] + V[3], padded rows
+    const size_t lds = Lds<D>::TOTAL;      // K[3] + V[3], padded rows
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads / NQB);
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
@@ -661,21 +672,14 @@ int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causa
 }  // namespace
 
 int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    return launch_cfg<1, 2, 0, 0>(p, dtype, head_dim, causal, stream);      // NQB = 1, fragment prefetch distance 2
+    return launch_cfg<1, 2, 2, 0>(p, dtype, head_dim, causal, stream);      // NQB = 1, prefetch distance 2, staged softmax
 }
-// experimental variants for tools/prefill_ab.py (SFA_PREFILL_IMPL = 2, 3, 4)
+// diagnostic / A-B variants for tools/prefill_ab.py and tools/prefill_stamps.py (SFA_PREFILL_IMPL = 2..4)
 int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, int head_dim, bool causal,
                            hipStream_t stream) {
-    if (which == 2) return launch_cfg<1, 2, 1, 0>(p, dtype, head_dim, causal, stream);
-    if (which == 5) return launch_cfg<1, 2, 0, 2>(p, dtype, head_dim, causal, stream);     // stamps -> lse
-    if (which == 10) return launch_cfg<1, 2, 2, 0>(p, dtype, head_dim, causal, stream);    // staged softmax
-    if (which == 11) return launch_cfg<1, 2, 2, 2>(p, dtype, head_dim, causal, stream);    // staged softmax + stamps
-    if (which == 8) return launch_cfg<1, 2, 0, 8>(p, dtype, head_dim, causal, stream);     // mixed slot order
-    if (which == 9) return launch_cfg<1, 2, 0, 10>(p, dtype, head_dim, causal, stream);    // mixed order + stamps
-    if (which == 6) return launch_cfg<1, 2, 0, 4>(p, dtype, head_dim, causal, stream);     // alternating priority
-    if (which == 7) return launch_cfg<1, 2, 0, 6>(p, dtype, head_dim, causal, stream);     // alternating priority + stamps
-    if (which == 3) return launch_cfg<1, 2, 0, 1>(p, dtype, head_dim, causal, stream);
-    return launch_cfg<1, 2, 1, 1>(p, dtype, head_dim, causal, stream);
+    if (which == 2) return launch_cfg<1, 2, 0, 0>(p, dtype, head_dim, causal, stream);     // un-staged softmax slices
+    if (which == 3) return launch_cfg<1, 2, 2, 32>(p, dtype, head_dim, causal, stream);    // loads bunched after the barrier
+    return launch_cfg<1, 2, 2, 2>(p, dtype, head_dim, causal, stream);                     // in-kernel stamps -> lse buffer
 }
 
 }  // namespace sfa

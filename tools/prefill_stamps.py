@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-wave cycle shares of one workgroup's steps 8..15 (SFA_PREFILL_IMPL=5 build).
+"""Diagnostic: per-wave cycle shares of one workgroup's steps 8..15 (SFA_PREFILL_IMPL=4 build).
 Stamps: 0 start of H1, 1 end of H1 (before barrier), 2 after barrier, 3 end of H2."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SFA_PREFILL_IMPL"] = os.environ.get("STAMP_IMPL", "5")
+os.environ["SFA_PREFILL_IMPL"] = os.environ.get("STAMP_IMPL", "4")
 import torch
 import starflashattention_amd as sfa
 B, H, S, D = 16, 32, 4096, 128
