@@ -166,7 +166,7 @@ def main():
         traffic, traffic_src = None, None
         try:                    # committed PMC measurement of this same command (tools/profile_bench.sh)
             with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-                traffic = json.load(f)["prefill_kernel<Bf16, 128, true, 1, 2>"]["total_bytes"]
+                traffic = json.load(f)["prefill_kernel"]["total_bytes"]
                 traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
         except Exception:
             pass
@@ -183,7 +183,7 @@ def main():
                        "causal": causal, "parallelism": f"batch-shard x{world}"},
             "tflops_per_gpu": round(total_tflops / world, 2),
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal,NQB=1,PF=2>",
+            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal>",
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,

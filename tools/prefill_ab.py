@@ -6,13 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
 
-impls = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [0, 1]
+impls = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0, 1]
 causal = "--noncausal" not in sys.argv
 D = 64 if "--d64" in sys.argv else 128
 B, H, S = 16, 32, 4096
+for a in sys.argv[1:]:
+    if a.startswith("--shape="):          # --shape=B,H,S
+        B, H, S = (int(x) for x in a.split("=")[1].split(","))
+fp16 = "--fp16" in sys.argv
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
-q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).bfloat16() for _ in range(3))
+q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).to(torch.float16 if fp16 else torch.bfloat16) for _ in range(3))
 outs = {}
 flops = 4.0 * B * H * S * S * D / (2 if causal else 1)
 def run(impl, n):
@@ -35,4 +39,4 @@ ref = outs[impls[0]].float()
 for i in impls:
     ms = sorted(res[i]); med = ms[len(ms)//2]
     err = (outs[i].float() - ref).abs().max().item()
-    print(f"impl {i}: median {med:.3f} ms  min {ms[0]:.3f} ms  {flops/med/1e9:.1f} TFLOPS (best {flops/ms[0]/1e9:.1f})  max|diff vs impl {impls[0]}| = {err:.4g}", flush=True)
+    print(f"[B={B} H={H} S={S} D={D} {'fp16' if fp16 else 'bf16'} {'causal' if causal else 'full'}] impl {i}: median {med:.3f} ms  min {ms[0]:.3f} ms  {flops/med/1e9:.1f} TFLOPS (best {flops/ms[0]/1e9:.1f})  max|diff vs impl {impls[0]}| = {err:.4g}", flush=True)
