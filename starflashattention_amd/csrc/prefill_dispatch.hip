@@ -1,6 +1,10 @@
-// Picks the prefill kernel generation.  The software-pipelined kernel (prefill_kernel.hip) is the
-// product path; the baseline (prefill_baseline.hip) stays in the library as an in-process A/B
-// reference for tools/prefill_ab.py and can be forced with SFA_PREFILL_IMPL=0.
+// Picks the prefill kernel.
+//   auto (default): the 256-row software-pipelined kernel (prefill_kernel.hip) whenever the problem
+//     has at least one 256-row workgroup per CU; smaller problems take the 128-row geometry
+//     (prefill_kernel_bm128.hip: twice the workgroups, measured 5-14 % faster when the 256-row grid
+//     cannot fill the 256 CUs and 7-10 % slower when it can).  Both produce bit-identical results.
+//   SFA_PREFILL_IMPL=0 / 1 / 20 force the baseline generation / the 256-row / the 128-row kernel;
+//   2..4 are diagnostic variants (tools/prefill_ab.py, tools/prefill_stamps.py).
 #include <cstdlib>
 
 #include "prefill_common.h"
@@ -10,11 +14,16 @@ namespace sfa {
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     static const int impl = [] {
         const char *e = std::getenv("SFA_PREFILL_IMPL");
-        return e ? std::atoi(e) : 1;
+        return e ? std::atoi(e) : -1;
     }();
-    const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // A/B harness only: re-read every call
-    const int which = e ? std::atoi(e) : impl;
+    const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // tests / A-B harness: re-read every call
+    int which = e ? std::atoi(e) : impl;
+    if (which < 0) {
+        const long long wgs256 = (long long)p.B * p.Hq * ((p.Sq + 255) / 256);
+        which = wgs256 < 256 ? 20 : 1;
+    }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
+    if (which == 20) return launch_prefill_bm128(p, dtype, head_dim, causal, stream);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);
 }

@@ -60,10 +60,17 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
 ]
 
 
+# every kernel the dispatcher can pick must pass on its own: the 256-row pipelined kernel, the
+# 128-row geometry for small grids, the baseline generation kept for A/B runs, and the auto choice
+IMPLS = {"auto": "-1", "rows256": "1", "rows128": "20", "baseline": "0"}
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_hq%d_hkv%d_sq%d_sk%d_d%d" % c)
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_prefill_vs_oracle(sfa, case, causal, dtype):
+@pytest.mark.parametrize("impl", list(IMPLS))
+def test_prefill_vs_oracle(sfa, monkeypatch, case, causal, dtype, impl):
+    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
     B, Hq, Hkv, Sq, Sk, D = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     q = round_to(rng.standard_normal((B, Hq, Sq, D)), dtype)
@@ -112,9 +119,11 @@ def test_prefill_strided_layouts_and_out(sfa):
     np.testing.assert_allclose(o3.float().cpu().numpy(), want, atol=2e-3, rtol=2e-3)
 
 
-def test_prefill_forced_rescale_branch(sfa):
+@pytest.mark.parametrize("impl", ["rows256", "rows128"])
+def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
     """cdna_hip_programming.md rule 26: force the online-softmax max to jump at a chosen tile --
     one K row far larger than the rest, placed late in the sequence, against every Q row."""
+    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
     rng = np.random.default_rng(9)
     B, H, S, D = 1, 2, 640, 128
     q = round_to(rng.standard_normal((B, H, S, D)), "bf16")
@@ -129,11 +138,13 @@ def test_prefill_forced_rescale_branch(sfa):
             np.testing.assert_allclose(o, want, atol=1.6e-2, rtol=1.6e-2)
 
 
-def test_prefill_properties_at_bench_size(sfa):
+@pytest.mark.parametrize("impl", ["rows256", "rows128"])
+def test_prefill_properties_at_bench_size(sfa, monkeypatch, impl):
     """BASELINE configs 2/3 are too large for the CPU oracle, so check size-independent properties
     at full size: (1) all-equal V rows -> output equals that row exactly-ish (softmax weights sum
     to 1); (2) causal output row i depends only on keys <= i: truncating the sequence leaves the
     first rows bit-identical; (3) a spot-checked slice of heads against the oracle."""
+    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     B, H, S, D = 2, 4, 4096, 128
