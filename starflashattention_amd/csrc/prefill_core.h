@@ -258,5 +258,29 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     }
 }
 
+// Epilogue store of one 32-row query block: O[row][0..D) = o^T * inv, converted to 16 bit.
+// The 32x32 accumulator leaves every output row split across the two lane halves (lane l: columns
+// 8g..8g+3 of group g, lane l+32: 8g+4..8g+7), i.e. 8-byte stores.  One v_permlane32_swap per dword
+// trades group g's upper half against group g+1's lower half, after which each lane owns 16
+// contiguous bytes: half as many (twice as wide) store instructions -- the tail is store-ISSUE
+// bound (cdna_hip_programming.md T21).  `row` points at column 0 of this lane's output row.
+template <class Tr, int D>
+__device__ __forceinline__ void store_o_row(uint16_t *row, const f32x16 (&o)[D / 32], float inv, int h2) {
+#pragma unroll
+    for (int d = 0; d < D / 32; ++d) {
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            uint32_t ax = Tr::pack2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
+            uint32_t ay = Tr::pack2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+            uint32_t bx = Tr::pack2(o[d][4 * g + 4] * inv, o[d][4 * g + 5] * inv);
+            uint32_t by = Tr::pack2(o[d][4 * g + 6] * inv, o[d][4 * g + 7] * inv);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            // lower lanes: [own g | upper's g] = columns 8g..8g+7; upper lanes: [lower's g+1 | own g+1]
+            *reinterpret_cast<uint4 *>(row + 32 * d + 8 * g + 8 * h2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+    }
+}
+
 }  // namespace prefill
 }  // namespace sfa

@@ -1,6 +1,6 @@
 // Picks the prefill kernel.
 //   auto (default): the 256-row software-pipelined kernel (prefill_kernel.hip) whenever the problem
-//     has at least one 256-row workgroup per CU; smaller problems take the 128-row geometry
+//     has at least one of its workgroups (a pair of 256-row q-tiles) per CU; smaller problems take the 128-row geometry
 //     (prefill_kernel_bm128.hip: twice the workgroups, measured 5-14 % faster when the 256-row grid
 //     cannot fill the 256 CUs and 7-10 % slower when it can).  Both produce bit-identical results.
 //   SFA_PREFILL_IMPL=0 / 1 / 20 force the baseline generation / the 256-row / the 128-row kernel;
@@ -19,8 +19,9 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // tests / A-B harness: re-read every call
     int which = e ? std::atoi(e) : impl;
     if (which < 0) {
-        const long long wgs256 = (long long)p.B * p.Hq * ((p.Sq + 255) / 256);
-        which = wgs256 < 256 ? 20 : 1;
+        // the 256-row kernel runs one workgroup per PAIR of q-tiles
+        const long long wgs = (long long)p.B * p.Hq * (((p.Sq + 255) / 256 + 1) / 2);
+        which = wgs < 256 ? 20 : 1;
     }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
     if (which == 20) return launch_prefill_bm128(p, dtype, head_dim, causal, stream);

@@ -254,17 +254,8 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
     const float ltot = half_sum(acc.lsum[0]);
     const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
     if (qrow < p.Sq) {
-        uint16_t *op = p.o + b * p.os[0] + h * p.os[1] + (long long)qrow * p.os[2] + 4 * h2;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = Tr::pack2(acc.o[0][d][4 * g + 0] * inv, acc.o[0][d][4 * g + 1] * inv);
-                w.y = Tr::pack2(acc.o[0][d][4 * g + 2] * inv, acc.o[0][d][4 * g + 3] * inv);
-                *reinterpret_cast<uint2 *>(op + 32 * d + 8 * g) = w;
-            }
-        }
+        uint16_t *orow = p.o + b * p.os[0] + h * p.os[1] + (long long)qrow * p.os[2];
+        store_o_row<Tr, D>(orow, acc.o[0], inv, h2);
         if (p.lse && h2 == 0) {
             const float lse = ltot > 0.f ? (acc.msc[0] + __log2f(ltot)) * kLn2 : ninf();
             p.lse[((long long)b * p.Hq + h) * p.Sq + qrow] = lse;
