@@ -50,6 +50,8 @@
 //     (Workgroup-level stamps: prologue 5.4 us + epilogue 2.2 us + ~3.7 us dispatch gap per workgroup
 //     against ~75 us of tile steps at S=4096 causal -- tools/prefill_wg_stamps.py.)
 //   * blockIdx -> (head, q-tile pair) is XCD-aware (prefill_common.h).
+#include <cstdlib>
+
 #include "prefill_core.h"
 
 namespace sfa {
@@ -73,13 +75,22 @@ prefill_kernel(const PrefillKernelParams p) {
     static_assert(NLD >= 1 && NLD <= 2, "staging registers are named kr0, kr1");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // ---- which (batch, head) and which pair of q-tiles ----
-    // p.nq_tiles counts PAIRS here (launcher); pair i of n = ceil(Sq/256) q-tiles is (n-1-i, i).
-    const BlockCoord bc = block_coord(p);       // .qt = pair index, heaviest pair first
+    // ---- which (batch, head) and which q-tiles ----
+    // n = ceil(Sq/256) q-tiles form ceil(n/2) balanced pairs (n-1-i, i); a workgroup owns
+    // p.pairs_per_wg (1 or 2) of them: slot j of p.nq_tiles slots per head takes pairs j and
+    // j + nq_tiles.  Items (q-tiles) are walked heavy, light, heavy, light.
+    const BlockCoord bc = block_coord(p);       // .qt = slot index
     if (bc.bh >= p.B * p.Hq) return;
     const int nq = (p.Sq + kBM - 1) / kBM;
-    const int qt_a = nq - 1 - bc.qt, qt_b = bc.qt;
-    const int n_items = (qt_a == qt_b) ? 1 : 2;
+    const int npairs = (nq + 1) / 2;
+    constexpr int MAX_ITEMS = 4;
+    auto item_qt = [&](int it) -> int {         // q-tile of item `it`, or -1 if the item does not exist
+        const int pr = bc.qt + (it >> 1) * p.nq_tiles;
+        if ((it >> 1) >= p.pairs_per_wg || pr >= npairs) return -1;
+        const int heavy = nq - 1 - pr;
+        if (it & 1) return heavy == pr ? -1 : pr;
+        return heavy;
+    };
     // DIAG & 2 (diagnostic build only): workgroup-level stamps (start, loop entry of item 0, end of
     // item 0's loop, end) as u64 pairs (s_memtime, s_memrealtime) behind the per-step stamps in p.lse
     auto wg_stamp = [&](int which) {
@@ -106,9 +117,10 @@ prefill_kernel(const PrefillKernelParams p) {
         if (CAUSAL) kv_end = min(p.Sk, qt * kBM + kBM + coff);
         return kv_end > 0 ? (kv_end + kBN - 1) / kBN : 0;
     };
-    const int nt_a = item_tiles(qt_a);
-    const int nt_b = n_items > 1 ? item_tiles(qt_b) : 0;
-    const int nt_all = nt_a + nt_b;             // length of the tile stream
+    auto item_nt = [&](int it) -> int { const int qt = item_qt(it); return qt < 0 ? 0 : item_tiles(qt); };
+    // stream position where each item's tiles start (cumulative)
+    const int cs1 = item_nt(0), cs2 = cs1 + item_nt(1), cs3 = cs2 + item_nt(2);
+    const int nt_all = cs3 + item_nt(3);         // length of the tile stream
 
     // ---- staging: thread owns chunks (row st_row + i*ROWSTEP, chunk st_ch), i < NLD, of every tile ----
     const int st_row = tid / CPR, st_ch = tid % CPR;
@@ -121,13 +133,13 @@ prefill_kernel(const PrefillKernelParams p) {
     uint4 kr0, kr1, vr0, vr1;       // plain scalars: arrays of these ended up in scratch
     kr0 = kr1 = vr0 = vr1 = make_uint4(0, 0, 0, 0);
 
-    // Branch-free staging loads.  Stream position -> K/V tile: item A's tiles, then item B's (indices
-    // restart at 0, same K/V); positions past the end re-read the last tile of the sequence (never
+    // Branch-free staging loads.  Stream position -> K/V tile: the items' tiles back to back (indices
+    // restart at 0 for every item, same K/V); positions past the end re-read the last tile of the sequence (never
     // used).  The one ragged tile (Sk % 64 != 0) swaps in a row-clamped lane offset with a v_cndmask.
     const int n_kv_tiles = (p.Sk + kBN - 1) / kBN;
     const int ragged_tile = (p.Sk % kBN) ? n_kv_tiles - 1 : -1;
     auto tile_of = [&](int pos) -> int {        // scalar
-        const int tix = pos < nt_a ? pos : pos - nt_a;
+        const int tix = pos < cs1 ? pos : pos < cs2 ? pos - cs1 : pos < cs3 ? pos - cs2 : pos - cs3;
         return min(tix, n_kv_tiles - 1);
     };
     const int row0_ = st_row, row1_ = st_row + ROWSTEP;
@@ -185,7 +197,7 @@ prefill_kernel(const PrefillKernelParams p) {
     // barrier depends on what it publishes.  Buffer safety with ONE barrier per tile: K(t+2)
     // overwrites K(t-1), last read in H1(t-1), and V(t+1) overwrites V(t-2), last read in H2(t-2)
     // -- both before barrier(t-1).
-    load_q(qt_a);
+    load_q(item_qt(0));
     uint4 kx0, kx1;                             // K(1), prologue only
     kx0 = kx1 = make_uint4(0, 0, 0, 0);
     if (nt_all > 0) {
@@ -237,10 +249,13 @@ prefill_kernel(const PrefillKernelParams p) {
         }
     };
 
-    for (int item = 0; item < n_items; ++item) {
-        const int qt = item == 0 ? qt_a : qt_b;
-        const int tbase = item == 0 ? 0 : nt_a;             // stream position of this item's tile 0
-        const int nt = item == 0 ? nt_a : nt_b;             // tiles the workgroup walks for this item
+    for (int item = 0; item < MAX_ITEMS; ++item) {
+        const int qt = item_qt(item);
+        if (qt < 0) continue;
+        const int tbase = item == 0 ? 0 : item == 1 ? cs1 : item == 2 ? cs2 : cs3;    // stream position of tile 0
+        const int nt = item_tiles(qt);                      // tiles the workgroup walks for this item
+        int qt_next = -1;                                   // the next item that exists, if any
+        for (int j = item + 1; j < MAX_ITEMS && qt_next < 0; ++j) qt_next = item_qt(j);
         const int q0 = qt * kBM;
         const int wq0 = q0 + 32 * wave;                     // this wave's first query row
         const int qrow = wq0 + l31;
@@ -328,7 +343,7 @@ prefill_kernel(const PrefillKernelParams p) {
             SFA_ADVANCE();
             ++t;
         }
-        if (item + 1 < n_items) load_q(qt_b);
+        if (qt_next >= 0) load_q(qt_next);
         // ---- idle steps (causal: tiles beyond this wave's diagonal): keep staging for the others ----
         for (; t < tend; ++t) {
             SFA_STAGE_AND_SYNC(t);
@@ -358,7 +373,15 @@ template <class Tr, int D, int PF, int ORD, int DIAG>
 int launch_t(const PrefillKernelParams &p_in, bool causal, hipStream_t stream) {
     PrefillKernelParams p = p_in;
     const int nq = (p.Sq + kBM - 1) / kBM;
-    p.nq_tiles = (nq + 1) / 2;                 // q-tile PAIRS (n-1-i, i)
+    const int npairs = (nq + 1) / 2;           // balanced q-tile pairs (n-1-i, i)
+    // One pair per workgroup.  Two pairs (half the dispatches and staging prologues again) are
+    // supported and tested, but measured 920 vs 941 TFLOPS on the headline shape, so they stay opt-in.
+    p.pairs_per_wg = 1;
+    if (const char *e = std::getenv("SFA_PREFILL_PAIRS")) {     // tests / A-B runs: force 1 or 2
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2) p.pairs_per_wg = v;
+    }
+    p.nq_tiles = (npairs + p.pairs_per_wg - 1) / p.pairs_per_wg;      // workgroup slots per head
     const size_t lds = Lds<D>::TOTAL;          // K[3] + V[3], padded rows
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
     static bool attr_set = false;       // idempotent; a race only repeats the call

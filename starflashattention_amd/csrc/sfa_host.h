@@ -38,7 +38,8 @@ struct PrefillKernelParams {
     int B, Hq, Hkv, Sq, Sk;
     long long qs[3], ks[3], vs[3], os[3];   // {batch, head, seq} strides (elements)
     float scale_log2;
-    int nq_tiles;           // ceil(Sq / 256)
+    int nq_tiles;           // workgroup slots per (batch, head) -- set by each kernel's launcher
+    int pairs_per_wg;       // prefill_kernel.hip: balanced q-tile pairs one workgroup walks (1 or 2)
     int bh_per_xcd;         // ceil(B*Hq / 8)
 };
 

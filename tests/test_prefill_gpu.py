@@ -57,12 +57,20 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
     (1, 2, 2, 100, 333, 128),      # Sq < Sk: bottom-right aligned causal
     (1, 1, 1, 333, 100, 128),      # Sq > Sk: the first rows see no key under the causal mask
     (1, 8, 8, 1024, 1024, 128),
+    (1, 2, 2, 1280, 1280, 128),    # 5 q-tiles: two pairs + an unpaired middle tile
+    (1, 1, 1, 1800, 1800, 64),     # 8 q-tiles, ragged last tile
 ]
 
 
 # every kernel the dispatcher can pick must pass on its own: the 256-row pipelined kernel, the
 # 128-row geometry for small grids, the baseline generation kept for A/B runs, and the auto choice
-IMPLS = {"auto": "-1", "rows256": "1", "rows128": "20", "baseline": "0"}
+IMPLS = {"auto": "-1", "rows256": "1", "rows256x2": "1", "rows128": "20", "baseline": "0"}
+# rows256x2: the 256-row kernel with TWO q-tile pairs per workgroup (what large grids get)
+
+
+def select_impl(monkeypatch, impl):
+    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
+    monkeypatch.setenv("SFA_PREFILL_PAIRS", "2" if impl == "rows256x2" else "1" if impl == "rows256" else "0")
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_hq%d_hkv%d_sq%d_sk%d_d%d" % c)
@@ -70,7 +78,7 @@ IMPLS = {"auto": "-1", "rows256": "1", "rows128": "20", "baseline": "0"}
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("impl", list(IMPLS))
 def test_prefill_vs_oracle(sfa, monkeypatch, case, causal, dtype, impl):
-    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
+    select_impl(monkeypatch, impl)
     B, Hq, Hkv, Sq, Sk, D = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     q = round_to(rng.standard_normal((B, Hq, Sq, D)), dtype)
@@ -119,11 +127,11 @@ def test_prefill_strided_layouts_and_out(sfa):
     np.testing.assert_allclose(o3.float().cpu().numpy(), want, atol=2e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("impl", ["rows256", "rows128"])
+@pytest.mark.parametrize("impl", ["rows256", "rows256x2", "rows128"])
 def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
     """cdna_hip_programming.md rule 26: force the online-softmax max to jump at a chosen tile --
     one K row far larger than the rest, placed late in the sequence, against every Q row."""
-    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
+    select_impl(monkeypatch, impl)
     rng = np.random.default_rng(9)
     B, H, S, D = 1, 2, 640, 128
     q = round_to(rng.standard_normal((B, H, S, D)), "bf16")
@@ -138,13 +146,13 @@ def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
             np.testing.assert_allclose(o, want, atol=1.6e-2, rtol=1.6e-2)
 
 
-@pytest.mark.parametrize("impl", ["rows256", "rows128"])
+@pytest.mark.parametrize("impl", ["rows256", "rows256x2", "rows128"])
 def test_prefill_properties_at_bench_size(sfa, monkeypatch, impl):
     """BASELINE configs 2/3 are too large for the CPU oracle, so check size-independent properties
     at full size: (1) all-equal V rows -> output equals that row exactly-ish (softmax weights sum
     to 1); (2) causal output row i depends only on keys <= i: truncating the sequence leaves the
     first rows bit-identical; (3) a spot-checked slice of heads against the oracle."""
-    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
+    select_impl(monkeypatch, impl)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     B, H, S, D = 2, 4, 4096, 128
