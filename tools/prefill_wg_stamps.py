@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic (SFA_PREFILL_IMPL=4 build): where a workgroup's life goes -- prologue, main loop,
-epilogue -- and the gap between consecutive workgroups on one CU.  usage: [--noncausal] [--shape=B,H,S]"""
+"""Diagnostic (SFA_PREFILL_IMPL=4 build): where a workgroup's life goes.  Stamps: 0 workgroup start,
+1 first q-tile's loop entry (end of the staging prologue), 2 end of the first q-tile's loop, 3 end of
+the workgroup (second q-tile of the pair included).  usage: [--noncausal] [--shape=B,H,S]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SFA_PREFILL_IMPL"] = "4"
@@ -17,7 +18,7 @@ q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).bfloat16() for _ i
 for _ in range(3):
     out, lse = sfa.flash_attn_fwd(q, k, v, causal=causal, return_lse=True)
 torch.cuda.synchronize()
-n = min(2048, 8 * ((B * H + 7) // 8) * ((S + 255) // 256))
+n = min(2048, 8 * ((B * H + 7) // 8) * ((((S + 255) // 256) + 1) // 2))
 raw = lse.view(-1).view(torch.int64)[1024: 1024 + n * 8].view(n, 4, 2).cpu().double()
 cyc, rt = raw[:, :, 0], raw[:, :, 1]          # shader cycles, 100 MHz ticks
 ok = (rt[:, 3] > rt[:, 0]) & (rt[:, 0] > 0)
@@ -25,8 +26,8 @@ cyc, rt = cyc[ok], rt[ok]
 us = lambda a, b_: ((rt[:, b_] - rt[:, a]) * 0.01)
 print(f"[B={B} H={H} S={S} causal={causal}] workgroups sampled: {int(ok.sum())}")
 print(f"  prologue  (start -> loop entry): {us(0,1).mean():7.2f} us   (min {us(0,1).min():.2f}, max {us(0,1).max():.2f})")
-print(f"  main loop (entry -> exit)      : {us(1,2).mean():7.2f} us")
-print(f"  epilogue  (exit -> end)        : {us(2,3).mean():7.2f} us   (min {us(2,3).min():.2f}, max {us(2,3).max():.2f})")
+print(f"  first q-tile's steps           : {us(1,2).mean():7.2f} us")
+print(f"  its epilogue + second q-tile   : {us(2,3).mean():7.2f} us   (min {us(2,3).min():.2f}, max {us(2,3).max():.2f})")
 clk = ((cyc[:, 3] - cyc[:, 0]) / (rt[:, 3] - rt[:, 0]) * 100).median()
 print(f"  shader clock inside the kernel : {clk:7.0f} MHz")
 # gap: sort starts; for the wave of first-generation WGs (earliest 256 starts) find per-CU successor is unknown,
