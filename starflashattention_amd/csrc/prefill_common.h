@@ -46,7 +46,8 @@ __device__ __forceinline__ BlockCoord block_coord(const PrefillKernelParams &p) 
 int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, int head_dim, bool causal,
                            hipStream_t stream);
-int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
+                         int force = 0);
 int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 
 }  // namespace sfa

@@ -53,6 +53,9 @@ struct Acc {
     f32x16 o[NQB][D / 32];      // O^T accumulators
     float msc[NQB];             // reference max the exponentials are taken against (log2 units)
     float lsum[NQB];            // this lane's share of the running row sum
+    f32x16 cinit[NQB];          // prescaled mode (ORD 6): -msc in all 16 registers, the C operand of
+                                // the first QK^T MFMA, so scores come out of the MFMA already
+                                // relative to the reference max and in log2 units
 };
 
 // One pipelined half-step in explicit slot order, for all NQB query blocks of the wave:
@@ -66,6 +69,31 @@ struct Acc {
 //   mxN[q]    out: this lane's max over the 16 new scores
 //   mask_o    bit q set: sO[q] holds keys that must be masked (diagonal / ragged tiles)
 //   PF        how many slots ahead of its MFMAs a fragment is read
+// Prescaled mode: finish the row max of freshly computed scores s (already relative to acc.msc, log2
+// units).  Lazy rescale: only when some row of the wave rose more than kRescaleThr above the reference
+// do O, the row sum, the pending scores and cinit move to the new reference (wave-uniform, rare).
+template <int D, int NQB>
+__device__ __forceinline__ void finish_prescaled(f32x16 &s, Acc<D, NQB> &acc, int q, float mxl, int masked,
+                                                 int kbase, int h2, int lim) {
+    if (masked) {                                       // wave-uniform, diagonal / ragged tiles only
+        mask_half(s, kbase, h2, lim);
+        mxl = lane_rowmax(s);
+    }
+    const float mx = half_max(mxl);                     // both lane halves hold the same query
+    if (__any(mx > kRescaleThr)) {
+        const float d = fmaxf(mx, 0.f);                 // rows that did not rise keep their reference
+        const float alpha = fast_exp2(-d);
+        acc.msc[q] += d;
+        acc.lsum[q] *= alpha;
+#pragma unroll
+        for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.o[q][b][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] -= d; acc.cinit[q][r] = -acc.msc[q]; }
+    }
+}
+
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
 template <class Tr, int D, int NQB, int PF, int ORD, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook, class PvHook = NoHook, int PH = 1 - HN>
@@ -82,6 +110,12 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     constexpr int KS = Lds<D>::KS, VS = Lds<D>::VS;
     constexpr int EP = 16 / NPV;            // elements per early PV slot     (elements 8..15)
     constexpr int EM = 32 / NPV;            // new scores max-ed per late PV slot
+    // ORD == 6, "prescaled": Q was multiplied by scale*log2(e) when it was loaded and the first
+    // QK^T MFMA starts from C = -msc, so sO IS the exp2 argument: no scale/subtract VALU pass.  The
+    // row max of the new scores is finished at the END of the half-step that computed them (mask_o /
+    // kbase_o then describe sN, and mxO / mxN are unused), so msc is final before the next
+    // half-step's first MFMA reads cinit.
+    constexpr bool PS = (ORD == 6);
 
     auto ld_k = [&](int ks) -> Vec {
         return bitcast<Vec>(*reinterpret_cast<const uint4 *>(kb + KS * 32 * HN + 32 * ks));
@@ -108,14 +142,18 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[0], qf[q][0], z);
+        for (int q = 0; q < NQB; ++q) sN[q] = Tr::mfma32(kf[0], qf[q][0], PS ? acc.cinit[q] : z);
     } else {
 #pragma unroll
         for (int i = 0; i < PF; ++i) vf[i] = ld_v(i);
     }
-    float msafe[NQB];
+    if (PS && NKS >= 8 && DO_QK) {    // stage X of pair 0 already in slot 0
 #pragma unroll
-    for (int q = 0; q < NQB; ++q) {
+        for (int q = 0; q < NQB; ++q) { sO[q][0] = fast_exp2(sO[q][0]); sO[q][1] = fast_exp2(sO[q][1]); }
+    }
+    float msafe[NQB] = {};
+#pragma unroll
+    for (int q = 0; q < NQB && !PS; ++q) {
         float mxl = mxO[q];
         if (mask_o & (1 << q)) {                        // wave-uniform, diagonal / ragged tiles only
             mask_half(sO[q], kbase_o, h2, lim[q]);
@@ -137,13 +175,15 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     SFA_FENCE();
 
     uint32_t pk[NQB][8];                    // P^T packed: pk[q][4k .. 4k+3] is the B operand of k-step k
+    // (v_pk_fma_f32 / v_pk_add_f32 on register pairs halve the instruction count of the scale and
+    // row-sum passes but measured 3 % SLOWER than the scalar forms: 884 vs 915 TFLOPS)
     float rs0[NQB], rs1[NQB];
 #pragma unroll
     for (int q = 0; q < NQB; ++q) { rs0[q] = 0.f; rs1[q] = 0.f; }
     auto soft1 = [&](int e) {               // element e of every query block; packs completed pairs
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
-            sO[q][e] = fast_exp2(fmaf(sO[q][e], c2, -msafe[q]));
+            sO[q][e] = PS ? fast_exp2(sO[q][e]) : fast_exp2(fmaf(sO[q][e], c2, -msafe[q]));
             if (e & 1) { rs1[q] += sO[q][e]; pk[q][e >> 1] = Tr::pack2(sO[q][e - 1], sO[q][e]); }
             else { rs0[q] += sO[q][e]; }
         }
@@ -155,7 +195,7 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     // Pair g (elements 2g, 2g+1) does F in soft-slot g, X in g+1, A in g+2; soft-slot u is QK slot
     // u+1 for u < NKS-1 and PV slot u-(NKS-1) after that.  Needs NKS >= 8 (pairs 0..3 packed before
     // the first PV MFMA, pairs 4..7 before PV slot NPV/2).
-    constexpr bool STAGED = (ORD == 2) && (NKS >= 8) && DO_QK;     // ORD: 0 = plain slices, 2 = staged, 1 = VALU before MFMA (A/B: no gain)
+    constexpr bool STAGED = (ORD == 2 || ORD == 6) && (NKS >= 8) && DO_QK;     // ORD: 0 = plain slices, 2 = staged, 1 = VALU before MFMA (A/B: no gain)
     auto stage_f = [&](int g) {
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -179,6 +219,12 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
         }
     };
     auto staged_slot = [&](int u) {
+        if (PS) {                           // two stages: X in soft-slot g, A in g+1
+            const int w = u + 1;            // (slot 0 already did X of pair 0)
+            if (w - 1 >= 0 && w - 1 < 8) stage_a(w - 1);
+            if (w >= 0 && w < 8) stage_x(w);
+            return;
+        }
         if (u - 2 >= 0 && u - 2 < 8) stage_a(u - 2);
         if (u - 1 >= 0 && u - 1 < 8) stage_x(u - 1);
         if (u < 8) stage_f(u);
@@ -254,7 +300,12 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
         acc.lsum[q] += rs0[q] + rs1[q];
-        mxN[q] = fmaxf(m0[q], m1[q]);
+        if (!PS) mxN[q] = fmaxf(m0[q], m1[q]);
+    }
+    if (PS && DO_QK) {
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) finish_prescaled<D, NQB>(sN[q], acc, q, fmaxf(m0[q], m1[q]),
+                                                               (mask_o >> q) & 1, kbase_o, h2, lim[q]);
     }
 }
 

@@ -2,9 +2,14 @@
 //   auto (default): the 256-row software-pipelined kernel (prefill_kernel.hip) whenever the problem
 //     has at least one of its workgroups (a pair of 256-row q-tiles) per CU; smaller problems take the 128-row geometry
 //     (prefill_kernel_bm128.hip: twice the workgroups, measured 5-14 % faster when the 256-row grid
-//     cannot fill the 256 CUs and 7-10 % slower when it can).  Both produce bit-identical results.
-//   SFA_PREFILL_IMPL=0 / 1 / 20 force the baseline generation / the 256-row / the 128-row kernel;
-//   2..4 are diagnostic variants (tools/prefill_ab.py, tools/prefill_stamps.py).
+//     cannot fill the 256 CUs and 7-10 % slower when it can).
+//     Each geometry comes in two numeric flavours: exact scale (scores = fp32 QK^T times the scale in
+//     fp32) and prescaled Q (Q * scale * log2 e rounded to 16 bit once per q-tile, the scale pass
+//     gone from the inner loop: +5 %).  Calls that return the log-sum-exp get the exact flavour,
+//     output-only calls the prescaled one; within a flavour the two geometries are bit-identical.
+//   SFA_PREFILL_IMPL=0 / 1 / 20 force the baseline generation / the 256-row / the 128-row kernel
+//   (flavour by the rule above); 3 / 10 and 21 / 22 force prescaled / exact of the 256- and 128-row
+//   kernels; 2 and 4 are diagnostic variants (tools/prefill_ab.py, tools/prefill_stamps.py).
 #include <cstdlib>
 
 #include "prefill_common.h"
@@ -24,7 +29,7 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
         which = wgs < 256 ? 20 : 1;
     }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
-    if (which == 20) return launch_prefill_bm128(p, dtype, head_dim, causal, stream);
+    if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);
 }

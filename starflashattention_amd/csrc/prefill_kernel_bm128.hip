@@ -141,8 +141,11 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.o[0][d][r] = 0.f;
-    acc.msc[0] = ninf();
+    constexpr bool PS = (ORD == 6);
+    acc.msc[0] = PS ? 0.f : ninf();
     acc.lsum[0] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.cinit[0][r] = 0.f;
     const float c2 = p.scale_log2;
     const char *const k_rd = smem + L::KS * l31 + 16 * h2;
     const char *const v_rd = smem + L::V_BASE + L::VS * (4 * h2 + ((lane & 15) >> 2)) +
@@ -166,6 +169,15 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
     }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[0][ks]));    // see prefill_kernel.hip
+    if (PS) {                       // prescaled mode: fold scale * log2(e) into Q (prefill_core.h)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 w = bitcast<u32x4>(qf[0][ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = Tr::pack2(Tr::lo_f32(w[i]) * c2, Tr::hi_f32(w[i]) * c2);
+            qf[0][ks] = bitcast<Vec>(w);
+        }
+    }
     if (nt > 0) {
         SFA_STORE_K(0);
         SFA_STORE_V(0);
@@ -186,6 +198,17 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
         for (int i = 0; i < PF; ++i)
             kpre[i] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(k_rd + L::KTILE + 32 * i));
         mxA[0] = lane_rowmax(sA[0]);
+        if (PS) {                   // the first tile sets the reference outright
+            if (mask_bits(0)) {
+                mask_half(sA[0], 0, h2, lim[0]);
+                mxA[0] = lane_rowmax(sA[0]);
+            }
+            const float mx = half_max(mxA[0]);
+            const float m0 = (mx == ninf()) ? 0.f : mx;
+            acc.msc[0] = m0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sA[0][r] -= m0; acc.cinit[0][r] = -m0; }
+        }
     }
     __syncthreads();        // step 0 stores K(3) into K(0)'s buffer: every wave must be done with tile 0
 
@@ -223,7 +246,7 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
         };                                                                                          \
         h_block<Tr, D, 1, PF, ORD, 0, 0, true, true, decltype(st_hook), decltype(ld_hook), 0>(      \
             k_rd + k1_, v_rd + vcur, k_rd + k2_, qf, S_NEW, S_OLD, acc, c2, MX_OLD, MX_NEW,         \
-            mask_bits(t * kBN2), t * kBN2, h2, lim, kpre, st_hook, ld_hook);                        \
+            mask_bits((t + (PS ? 1 : 0)) * kBN2), (t + (PS ? 1 : 0)) * kBN2, h2, lim, kpre, st_hook, ld_hook); \
         __syncthreads();                                                                            \
         SFA_ADVANCE();                                                                              \
     } while (0)
@@ -276,25 +299,34 @@ prefill_kernel_bm128(const PrefillKernelParams p) {
 }
 
 template <class Tr, int D>
-int launch_t(const PrefillKernelParams &p_in, bool causal, hipStream_t stream) {
+int launch_t(const PrefillKernelParams &p_in, bool causal, int force, hipStream_t stream) {
     PrefillKernelParams p = p_in;
     p.nq_tiles = (p.Sq + kBM2 - 1) / kBM2;              // 128-row q-tiles
     const size_t lds = Lds<D, kBN2, 3, 2>::TOTAL;
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads2);
-    if (causal) hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, true, 2, 2>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, false, 2, 2>), grid, block, lds, stream, p);
+    // same policy as the 256-row kernel: prescaled Q for output-only calls, exact scale when the
+    // log-sum-exp is returned (SFA_PREFILL_IMPL 21 / 22 force one or the other)
+    const bool prescaled = force == 0 ? p.lse == nullptr : force == 1;
+    if (prescaled) {
+        if (causal) hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, true, 2, 6>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, false, 2, 6>), grid, block, lds, stream, p);
+    } else {
+        if (causal) hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, true, 2, 2>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, false, 2, 2>), grid, block, lds, stream, p);
+    }
     return check_launch("prefill_kernel_bm128");
 }
 
 }  // namespace
 
-int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
+                         int force) {   // force: 0 = by policy, 1 = prescaled, 2 = exact scale
     if (dtype == SFA_DTYPE_FP16) {
-        if (head_dim == 128) return launch_t<Fp16, 128>(p, causal, stream);
-        if (head_dim == 64) return launch_t<Fp16, 64>(p, causal, stream);
+        if (head_dim == 128) return launch_t<Fp16, 128>(p, causal, force, stream);
+        if (head_dim == 64) return launch_t<Fp16, 64>(p, causal, force, stream);
     } else if (dtype == SFA_DTYPE_BF16) {
-        if (head_dim == 128) return launch_t<Bf16, 128>(p, causal, stream);
-        if (head_dim == 64) return launch_t<Bf16, 64>(p, causal, stream);
+        if (head_dim == 128) return launch_t<Bf16, 128>(p, causal, force, stream);
+        if (head_dim == 64) return launch_t<Bf16, 64>(p, causal, force, stream);
     } else {
         return fail(SFA_ERR_BAD_DTYPE, "sfa_prefill_fwd: dtype %d is not fp16(0)/bf16(1)", dtype);
     }

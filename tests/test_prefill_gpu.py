@@ -62,15 +62,19 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
 ]
 
 
-# every kernel the dispatcher can pick must pass on its own: the 256-row pipelined kernel, the
-# 128-row geometry for small grids, the baseline generation kept for A/B runs, and the auto choice
-IMPLS = {"auto": "-1", "rows256": "1", "rows256x2": "1", "rows128": "20", "baseline": "0"}
-# rows256x2: the 256-row kernel with TWO q-tile pairs per workgroup (what large grids get)
+# every kernel the dispatcher can pick must pass on its own: the 256-row pipelined kernel (one or
+# two q-tile pairs per workgroup) and the 128-row geometry for small grids, each in its exact-scale
+# and its prescaled-Q flavour, the baseline generation kept for A/B runs, and the auto choice
+IMPLS = {"auto": "-1", "rows256": "10", "rows256x2": "10", "rows128": "22", "baseline": "0",
+         "prescaled256": "3", "prescaled256x2": "3", "prescaled128": "21"}
+# prescaled kernels carry Q*scale*log2(e) rounded to 16 bit: the log-sum-exp is good to input
+# precision (relative 2^-9 / 2^-12 of the scores), not to the fp32-class 2e-3 of the exact kernels
+LSE_TOL = {"exact": {"bf16": 2e-3, "fp16": 2e-3}, "prescaled": {"bf16": 1.5e-2, "fp16": 4e-3}}
 
 
 def select_impl(monkeypatch, impl):
     monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
-    monkeypatch.setenv("SFA_PREFILL_PAIRS", "2" if impl == "rows256x2" else "1" if impl == "rows256" else "0")
+    monkeypatch.setenv("SFA_PREFILL_PAIRS", "2" if impl.endswith("x2") else "1" if impl.endswith("256") else "0")
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_hq%d_hkv%d_sq%d_sk%d_d%d" % c)
@@ -88,7 +92,8 @@ def test_prefill_vs_oracle(sfa, monkeypatch, case, causal, dtype, impl):
     o, lse = run_fwd(sfa, q, k, v, dtype, causal, return_lse=True)
     np.testing.assert_allclose(o, want, atol=TOL[dtype], rtol=TOL[dtype])
     fin = np.isfinite(lse_want)
-    np.testing.assert_allclose(lse[fin], lse_want[fin], atol=2e-3, rtol=2e-3)
+    ltol = LSE_TOL["prescaled" if impl.startswith("prescaled") else "exact"][dtype]
+    np.testing.assert_allclose(lse[fin], lse_want[fin], atol=ltol, rtol=ltol)
     assert np.all(lse[~fin] == -np.inf)
     # error budget: no worse than 2x a plain same-dtype torch computation on the GPU
     dev = torch.device("cuda:0")
@@ -127,7 +132,10 @@ def test_prefill_strided_layouts_and_out(sfa):
     np.testing.assert_allclose(o3.float().cpu().numpy(), want, atol=2e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("impl", ["rows256", "rows256x2", "rows128"])
+NON_BASELINE = [i for i in IMPLS if i not in ("auto", "baseline")]
+
+
+@pytest.mark.parametrize("impl", NON_BASELINE)
 def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
     """cdna_hip_programming.md rule 26: force the online-softmax max to jump at a chosen tile --
     one K row far larger than the rest, placed late in the sequence, against every Q row."""
@@ -146,7 +154,7 @@ def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
             np.testing.assert_allclose(o, want, atol=1.6e-2, rtol=1.6e-2)
 
 
-@pytest.mark.parametrize("impl", ["rows256", "rows256x2", "rows128"])
+@pytest.mark.parametrize("impl", NON_BASELINE)
 def test_prefill_properties_at_bench_size(sfa, monkeypatch, impl):
     """BASELINE configs 2/3 are too large for the CPU oracle, so check size-independent properties
     at full size: (1) all-equal V rows -> output equals that row exactly-ish (softmax weights sum
@@ -169,6 +177,35 @@ def test_prefill_properties_at_bench_size(sfa, monkeypatch, impl):
     want = sdpa_ref(q[:1, :1].float().cpu().numpy(), k[:1, :1].float().cpu().numpy(),
                     v[:1, :1].float().cpu().numpy(), causal=True)
     np.testing.assert_allclose(full[:1, :1].float().cpu().numpy(), want, atol=1.6e-2, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_prefill_flavours_and_geometries(sfa, monkeypatch, causal, dtype):
+    """Within a numeric flavour the 256-row (1 or 2 pairs per workgroup) and 128-row kernels are
+    bit-identical; output-only calls take the prescaled flavour, LSE-returning calls the exact one."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, H, S, D = 1, 3, 1100, 128
+    q, k, v = (torch.randn(B, H, S, D, device=dev).to(TDT[dtype]) for _ in range(3))
+
+    def run(impl, lse):
+        select_impl(monkeypatch, impl)
+        r = sfa.flash_attn_fwd(q, k, v, causal=causal, return_lse=lse)
+        torch.cuda.synchronize()
+        return r[0] if lse else r
+
+    exact = run("rows256", True)
+    assert torch.equal(exact, run("rows256x2", True))
+    assert torch.equal(exact, run("rows128", True))
+    pre = run("prescaled256", False)
+    assert torch.equal(pre, run("prescaled256x2", False))
+    assert torch.equal(pre, run("prescaled128", False))
+    assert torch.equal(run("auto", True), exact)        # LSE requested -> exact scale
+    assert torch.equal(run("auto", False), pre)         # output only -> prescaled Q
+    # the two flavours differ by 16-bit rounding flips only
+    tol = TOL[dtype]
+    np.testing.assert_allclose(pre.float().cpu().numpy(), exact.float().cpu().numpy(), atol=tol, rtol=tol)
 
 
 def test_prefill_argument_errors(sfa):
