@@ -46,6 +46,10 @@ __device__ __forceinline__ float lane_rowmax(const f32x16 &s) {
 }
 
 #define SFA_FENCE() __builtin_amdgcn_sched_barrier(0)
+// sched_barrier orders the machine scheduler only: LLVM's IR passes still SINK a running sum or max
+// whose only use is at the end of the half-step down to that use -- all 16 row-sum adds (and in
+// prescaled mode the lane max) end up bunched behind the last PV MFMA.  Pinning each update to its
+// slot with an empty asm measured 1.5-2 % SLOWER, so the sinking is left alone.
 
 // Per-wave online-softmax state of NQB query blocks.
 template <int D, int NQB>

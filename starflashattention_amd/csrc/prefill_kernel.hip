@@ -140,9 +140,11 @@ prefill_kernel(const PrefillKernelParams p) {
     // used).  The one ragged tile (Sk % 64 != 0) swaps in a row-clamped lane offset with a v_cndmask.
     const int n_kv_tiles = (p.Sk + kBN - 1) / kBN;
     const int ragged_tile = (p.Sk % kBN) ? n_kv_tiles - 1 : -1;
-    auto tile_of = [&](int pos) -> int {        // scalar
-        const int tix = pos < cs1 ? pos : pos < cs2 ? pos - cs1 : pos < cs3 ? pos - cs2 : pos - cs3;
-        return min(tix, n_kv_tiles - 1);
+    auto tile_of = [&](int pos) -> int {        // scalar; selects, no branches
+        int base = pos >= cs1 ? cs1 : 0;
+        base = pos >= cs2 ? cs2 : base;
+        base = pos >= cs3 ? cs3 : base;
+        return min(pos - base, n_kv_tiles - 1);
     };
     const int row0_ = st_row, row1_ = st_row + ROWSTEP;
     const int last0_ = p.Sk - 1 - (n_kv_tiles - 1) * kBN;                  // last valid row of the last tile
@@ -153,13 +155,19 @@ prefill_kernel(const PrefillKernelParams p) {
     const unsigned or_v0 = (unsigned)min(row0_, last0_) * v_rowb + 16u * st_ch;
     const unsigned or_v1 = (unsigned)min(row1_, last0_) * v_rowb + 16u * st_ch;
     constexpr int NOPS = 2 * NLD;   // op n: even = K chunk n/2, odd = V chunk n/2
-    auto load_op = [&](int n, int pos_k, int pos_v) {
+    // Where the K and V tiles of two stream positions live: computed ONCE per step (scalar unit, a
+    // dozen instructions), not inside every load -- per-load index math put 20 scalar branches and
+    // ~100 SALU instructions per step into the MFMA slots.
+    struct TileSrc { const char *k, *v; bool rk, rv; };
+    auto tile_src = [&](int pos_k, int pos_v) -> TileSrc {
         const int tk = tile_of(pos_k), tv = tile_of(pos_v);
-        const bool rk = tk == ragged_tile, rv = tv == ragged_tile;
-        if (n == 0) kr0 = *reinterpret_cast<const uint4 *>(kg + tk * k_tile_bytes + (rk ? or_k0 : ow_k0));
-        if (n == 1) vr0 = *reinterpret_cast<const uint4 *>(vg + tv * v_tile_bytes + (rv ? or_v0 : ow_v0));
-        if (NLD > 1 && n == 2) kr1 = *reinterpret_cast<const uint4 *>(kg + tk * k_tile_bytes + (rk ? or_k1 : ow_k1));
-        if (NLD > 1 && n == 3) vr1 = *reinterpret_cast<const uint4 *>(vg + tv * v_tile_bytes + (rv ? or_v1 : ow_v1));
+        return TileSrc{kg + tk * k_tile_bytes, vg + tv * v_tile_bytes, tk == ragged_tile, tv == ragged_tile};
+    };
+    auto load_op = [&](int n, const TileSrc &ts) {
+        if (n == 0) kr0 = *reinterpret_cast<const uint4 *>(ts.k + (ts.rk ? or_k0 : ow_k0));
+        if (n == 1) vr0 = *reinterpret_cast<const uint4 *>(ts.v + (ts.rv ? or_v0 : ow_v0));
+        if (NLD > 1 && n == 2) kr1 = *reinterpret_cast<const uint4 *>(ts.k + (ts.rk ? or_k1 : ow_k1));
+        if (NLD > 1 && n == 3) vr1 = *reinterpret_cast<const uint4 *>(ts.v + (ts.rv ? or_v1 : ow_v1));
     };
     auto store_op = [&](int n, int kbuf, int vbuf) {
         if (n == 0) *reinterpret_cast<uint4 *>(k_w + kbuf) = kr0;
@@ -212,8 +220,9 @@ prefill_kernel(const PrefillKernelParams p) {
     uint4 kx0, kx1;                             // K(1), prologue only
     kx0 = kx1 = make_uint4(0, 0, 0, 0);
     if (nt_all > 0) {
+        const TileSrc ts0 = tile_src(0, 0);
 #pragma unroll
-        for (int n = 0; n < NOPS; ++n) load_op(n, 0, 0);
+        for (int n = 0; n < NOPS; ++n) load_op(n, ts0);
         const int t1 = tile_of(1);
         const bool r1 = t1 == ragged_tile;
         kx0 = *reinterpret_cast<const uint4 *>(kg + t1 * k_tile_bytes + (r1 ? or_k0 : ow_k0));
@@ -227,8 +236,11 @@ prefill_kernel(const PrefillKernelParams p) {
         if (NLD > 1) *reinterpret_cast<uint4 *>(k_w + L::KTILE + ROWSTEP * L::KS) = kx1;
     }
     __syncthreads();
+    {
+        const TileSrc ts1 = tile_src(2, 1);
 #pragma unroll
-    for (int n = 0; n < NOPS; ++n) load_op(n, 2, 1);
+        for (int n = 0; n < NOPS; ++n) load_op(n, ts1);
+    }
 
     int kcur = 0, vcur = 0;         // byte offsets of the K and V buffers of stream position t
     int t = 0;                      // stream position
@@ -245,7 +257,8 @@ prefill_kernel(const PrefillKernelParams p) {
         _Pragma("unroll") for (int n_ = 0; n_ < NOPS; ++n_)                                         \
             store_op(n_, SFA_NEXT3(k1_, L::KTILE), SFA_NEXT3(vcur, L::VTILE));                      \
         __syncthreads();                                                                            \
-        _Pragma("unroll") for (int n_ = 0; n_ < NOPS; ++n_) load_op(n_, (T) + 3, (T) + 2);          \
+        const TileSrc ts_ = tile_src((T) + 3, (T) + 2);                                             \
+        _Pragma("unroll") for (int n_ = 0; n_ < NOPS; ++n_) load_op(n_, ts_);                       \
         SFA_FENCE();                                                                                \
     } while (0)
 
@@ -345,10 +358,10 @@ prefill_kernel(const PrefillKernelParams p) {
             stamp(t, 1);
             __syncthreads();
             stamp(t, 2);
-            const int tk = t + 3, tv = t + 2;
+            const TileSrc ts = tile_src(t + 3, t + 2);
             auto ld_hook = [&](int i) {         // NOPS loads spread evenly over QK slots 1..NKS-1
 #pragma unroll
-                for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, tk, tv);
+                for (int n = (i - 1) * NOPS / (NKS - 1); n < i * NOPS / (NKS - 1); ++n) load_op(n, ts);
             };
             h_block<Tr, D, NQB, PF, ORD, 0, 1, true, true>(kb1, vb, kb1, qf, sA, sB, acc, c2, mxB, mxA,
                                                       mask_bits(kbase + 32 + PSO), kbase + 32 + PSO, h2, lim, kpre, ld_hook);

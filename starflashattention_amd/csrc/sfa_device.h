@@ -31,6 +31,7 @@ __device__ __forceinline__ To bitcast(const From &f) {
 struct Fp16 {
     using mfma_vec = f16x8;
     static constexpr int id = 0;
+    static constexpr uint32_t ones2 = 0x3C003C00u;      // (1.0, 1.0)
     static __device__ __forceinline__ float to_f32(uint16_t b) { return (float)bitcast<_Float16>(b); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return bitcast<uint16_t>((_Float16)f); }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -51,6 +52,7 @@ struct Fp16 {
 struct Bf16 {
     using mfma_vec = bf16x8;
     static constexpr int id = 1;
+    static constexpr uint32_t ones2 = 0x3F803F80u;      // (1.0, 1.0)
     static __device__ __forceinline__ float to_f32(uint16_t b) { return bitcast<float>((uint32_t)b << 16); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return bitcast<uint16_t>((__bf16)f); }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
