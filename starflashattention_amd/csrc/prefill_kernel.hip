@@ -197,14 +197,15 @@ prefill_kernel(const PrefillKernelParams p) {
     auto launder_q = [&]() {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[0][ks]));
-        if (PS) {                   // fold scale * log2(e) into Q once per q-tile
+    };
+    auto prescale_q = [&]() {       // prescaled mode: fold scale * log2(e) into Q once per q-tile
+        if (!PS) return;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                u32x4 w = bitcast<u32x4>(qf[0][ks]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 w = bitcast<u32x4>(qf[0][ks]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w[i] = Tr::pack2(Tr::lo_f32(w[i]) * c2, Tr::hi_f32(w[i]) * c2);
-                qf[0][ks] = bitcast<Vec>(w);
-            }
+            for (int i = 0; i < 4; ++i) w[i] = Tr::pack2(Tr::lo_f32(w[i]) * c2, Tr::hi_f32(w[i]) * c2);
+            qf[0][ks] = bitcast<Vec>(w);
         }
     };
 
@@ -293,8 +294,11 @@ prefill_kernel(const PrefillKernelParams p) {
         };
         const int tend = tbase + nt, twend = tbase + ntw;   // stream positions
 
-        if (item > 0) launder_q();                          // Q of this item was requested before the
-                                                            // previous item's TAIL step and epilogue
+        // Q of items > 0 was requested behind the previous item's TAIL step.  Unconditional (a no-op
+        // asm for item 0): under `if (item > 0)` hipcc still saw the first-iteration path as "Q loads
+        // in flight" and put a vmcnt wait in front of every QK^T MFMA of the main loop.
+        launder_q();
+        prescale_q();
         Acc<D, NQB> acc;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
