@@ -11,7 +11,8 @@
 //     global_load_dwordx4 fetches 64/(D/8) whole rows (4 rows for D=128): every 128-B line
 //     that is fetched is fully used, and neighbouring heads (blockIdx.x fastest) touch the
 //     same DRAM pages at about the same time.
-//   * K/V go straight to VGPRs (no LDS round trip: nothing is reused), U row-groups per
+//   * K/V go straight to VGPRs (no LDS round trip: nothing is reused; non-temporal loads when the
+//     caches exceed the Infinity Cache: +3 %; 8 or 2 waves per workgroup and U = 8 measured no better), U row-groups per
 //     step, register double-buffered so 2*U K-loads + 2*U V-loads (16 B/lane each) are in
 //     flight per wave; 4 waves/workgroup split the workgroup's key range.
 //   * q.k uses v_dot2c_f32_{f16,bf16}; the 16-lane (8 for D=64) row sum is 4 (3) DPP adds.
@@ -21,6 +22,8 @@
 //   * 64-bit addressing throughout (K alone is 8.6 G elements at B=256, M=8192, H=32).
 //   * The new token never round-trips through memory: the last split's wave 0 takes
 //     k_rot / v_new from registers, adds them to its softmax stream and writes the cache row.
+#include <cstdlib>
+
 #include "sfa_device.h"
 #include "sfa_host.h"
 
@@ -55,6 +58,17 @@ __device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
                       Tr::pack2(x[4], x[5]), Tr::pack2(x[6], x[7]));
 }
 
+// 16-byte cache-row load; NT = non-temporal (the cache rows are read exactly once per step)
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const uint16_t *p) {
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    if (NT) {
+        const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
 // Running softmax state of one lane group: max (log2 units), sum, and this lane's 8 output dims.
 struct Stream {
     float m, l, acc[8];
@@ -75,8 +89,8 @@ struct Stream {
     }
 };
 
-template <class Tr, int D, int U>
-__global__ void __launch_bounds__(kDecodeWaves * 64)
+template <class Tr, int D, int U, bool NT, int W = kDecodeWaves>
+__global__ void __launch_bounds__(W * 64)
 decode_kernel(const DecodeKernelParams p) {
     constexpr int LPR = D / 8;          // lanes per cache row
     constexpr int G = 64 / LPR;         // cache rows per wave-instruction
@@ -152,7 +166,7 @@ decode_kernel(const DecodeKernelParams p) {
     const int rows_per_split = (pos + S - 1) / S;
     const int r0 = min(pos, split * rows_per_split);
     const int r1 = min(pos, r0 + rows_per_split);
-    int per_wave = (r1 - r0 + kDecodeWaves - 1) / kDecodeWaves;
+    int per_wave = (r1 - r0 + W - 1) / W;
     per_wave = (per_wave + STEP - 1) / STEP * STEP;
     const int w0 = min(r1, r0 + wave * per_wave);
     const int w1 = min(r1, w0 + per_wave);
@@ -168,12 +182,12 @@ decode_kernel(const DecodeKernelParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);       // clamp: loads stay in range
-            kk[u] = *reinterpret_cast<const uint4 *>(kb + (long long)row * hd);
+            kk[u] = ld16<NT>(kb + (long long)row * hd);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);
-            vv[u] = *reinterpret_cast<const uint4 *>(vb + (long long)row * hd);
+            vv[u] = ld16<NT>(vb + (long long)row * hd);
         }
     };
     auto consume = [&](const uint4 (&kk)[U], const uint4 (&vv)[U], int t) {
@@ -245,7 +259,7 @@ decode_kernel(const DecodeKernelParams p) {
     }
 
     // ---- merge the workgroup's waves through LDS ----
-    __shared__ float red[kDecodeWaves][D + 2];
+    __shared__ float red[W][D + 2];
     if (grp == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[wave][sub * 8 + j] = st.acc[j];
@@ -256,7 +270,7 @@ decode_kernel(const DecodeKernelParams p) {
         Stream tot;
         tot.init();
 #pragma unroll
-        for (int w = 0; w < kDecodeWaves; ++w) {
+        for (int w = 0; w < W; ++w) {
             float a2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) a2[j] = red[w][tid * 8 + j];
@@ -311,9 +325,15 @@ decode_combine_kernel(const DecodeKernelParams p) {
 
 template <class Tr, int D>
 int launch_decode_t(const DecodeKernelParams &p, hipStream_t stream) {
-    constexpr int U = 4;
     dim3 grid(p.H, p.num_splits, p.B), block(kDecodeWaves * 64);
-    hipLaunchKernelGGL((decode_kernel<Tr, D, U>), grid, block, 0, stream, p);
+    // The cache rows are read exactly once per call.  When the two caches together do not fit the
+    // 256 MB Infinity Cache nothing of them survives until the next token's call either, so they are
+    // loaded non-temporally (config 4: 6.30 -> 6.51 TB/s); a small cache keeps the default policy
+    // and is re-read from the Infinity Cache / L2.  SFA_DECODE_NT=0/1 overrides (tests, A/B).
+    bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
+    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+    if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, 4, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((decode_kernel<Tr, D, 4, false>), grid, block, 0, stream, p);
     int rc = check_launch("decode_kernel");
     if (rc != SFA_OK) return rc;
     if (p.num_splits > 1) {

@@ -48,6 +48,8 @@ int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, i
                            hipStream_t stream);
 int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
                          int force = 0);
+int launch_prefill_x16(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
+                       int force = 0);
 int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 
 }  // namespace sfa

@@ -29,6 +29,7 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
         which = wgs < 256 ? 20 : 1;
     }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
+    if (which >= 30 && which <= 32) return launch_prefill_x16(p, dtype, head_dim, causal, stream, which - 30);
     if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);

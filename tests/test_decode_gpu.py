@@ -81,9 +81,12 @@ def check_against_oracle(sfa, qkv, kc, vc, lens, layer, rot, dtype, **kw):
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("num_splits", [0, 1, 3, 4])
-def test_decode_golden_reference_vectors(sfa, decode_golden, dtype, num_splits):
+@pytest.mark.parametrize("nt", ["0", "1"])
+def test_decode_golden_reference_vectors(sfa, monkeypatch, decode_golden, dtype, num_splits, nt):
     """Every golden case (seq_len around the 32/128 block and split boundaries), against the
-    reference's own outputs."""
+    reference's own outputs; with default and with non-temporal cache-row loads (the launcher picks
+    the latter for caches beyond the Infinity Cache -- bench sizes)."""
+    monkeypatch.setenv("SFA_DECODE_NT", nt)
     g = decode_golden
     qkv = bf16bits_to_f32(g["qkv_bf16bits"])
     kc = bf16bits_to_f32(g["k_cache_bf16bits"])

@@ -66,7 +66,8 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
 # two q-tile pairs per workgroup) and the 128-row geometry for small grids, each in its exact-scale
 # and its prescaled-Q flavour, the baseline generation kept for A/B runs, and the auto choice
 IMPLS = {"auto": "-1", "rows256": "10", "rows256x2": "10", "rows128": "22", "baseline": "0",
-         "prescaled256": "3", "prescaled256x2": "3", "prescaled128": "21"}
+         "prescaled256": "3", "prescaled256x2": "3", "prescaled128": "21",
+         "x16": "32", "prescaled_x16": "31"}       # the 16x16x32-MFMA kernel, exact / prescaled
 # prescaled kernels carry Q*scale*log2(e) rounded to 16 bit: the log-sum-exp is good to input
 # precision (relative 2^-9 / 2^-12 of the scores), not to the fp32-class 2e-3 of the exact kernels
 LSE_TOL = {"exact": {"bf16": 2e-3, "fp16": 2e-3}, "prescaled": {"bf16": 1.5e-2, "fp16": 4e-3}}
