@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFA_ABI_VERSION 1
+#define SFA_ABI_VERSION 2
 
 typedef enum sfa_status {
     SFA_OK = 0,
@@ -50,6 +50,16 @@ typedef enum sfa_dtype {
     SFA_DTYPE_FP16 = 0,          /* IEEE half  (the reference's only dtype)          */
     SFA_DTYPE_BF16 = 1
 } sfa_dtype;
+
+/* How the KV caches are laid out.  SFA_KV_BLMHD is the reference's documented layout
+ * (src/params.h:22-25, examples/python/testFlashDecoder.py:115-116) and what mha_fwd_cuda /
+ * run_flash_decoder use.  SFA_KV_BLHMD keeps every (batch, layer, head) contiguous -- the
+ * head-major layout the reference's kernel indexes internally (src/flash_attn.cu:617-619) --
+ * so one (b,h) streams a dense 2*M*D-byte region instead of 2*D-byte segments H*D*2 bytes apart. */
+typedef enum sfa_kv_layout {
+    SFA_KV_BLMHD = 0,            /* [batch, num_layer, memory_max_len, num_heads, head_dim] */
+    SFA_KV_BLHMD = 1             /* [batch, num_layer, num_heads, memory_max_len, head_dim] */
+} sfa_kv_layout;
 
 /* ---- library ------------------------------------------------------------------ */
 int sfa_abi_version(void);
@@ -70,7 +80,8 @@ const char *sfa_last_error(void);            /* thread-local, never NULL        
  *                                           fp32 math, result rounded to the 16-bit dtype
  *   k_cache[b, idx_layer, pos, h, :] = k;  v_cache[b, idx_layer, pos, h, :] = v
  *   o[b, h, :] = softmax(q . K[0..pos]^T * head_dim_inv) . V[0..pos]     (fp32 accumulate)
- * Caches are [batch, num_layer, memory_max_len, num_heads, head_dim], contiguous.
+ * Caches are [batch, num_layer, memory_max_len, num_heads, head_dim], contiguous
+ * (kv_layout = SFA_KV_BLMHD), or head-major with kv_layout = SFA_KV_BLHMD.
  * seq_len is NOT incremented (caller's job, as in the reference).
  * A sequence whose seq_len is out of range is left untouched in the caches, gets
  * NaN in o[b] and raises the sticky status word (see sfa_decode_poll_status).
@@ -102,6 +113,7 @@ typedef struct sfa_decode_args {
     /* -- replaces Flash_decoder_buffers -- */
     void *workspace;                /* >= sfa_decode_workspace_bytes(...), 256-B aligned */
     size_t workspace_bytes;
+    int kv_layout;                  /* sfa_kv_layout; 0 = the reference's layout (ABI v2) */
 } sfa_decode_args;
 
 /* Bytes of scratch sfa_decode needs for this shape (num_splits <= 0: the library's choice

@@ -151,6 +151,7 @@ at::Tensor mha_fwd_cuda(at::Tensor &qkv, at::Tensor &q_bias, at::Tensor &k_bias,
     a.idx_layer = input.idx_layer;
     a.num_splits = params.num_splits;
     a.dtype = dt;
+    a.kv_layout = SFA_KV_BLMHD;         // the reference's cache layout (src/params.h:22-25)
     const size_t need = sfa_decode_workspace_bytes(batch_size, num_heads, head_dim, memory_max_len, a.num_splits);
     at::Tensor &ws = workspace(dev, stream, need);
     a.workspace = ws.data_ptr();

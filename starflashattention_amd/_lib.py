@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libStarFlashAttention.so")
 
 SFA_OK = 0
+ABI_VERSION = 2          # SFA_ABI_VERSION in include/star_flash_attn.h
 SFA_ERR_SEQ_LEN_RANGE = -7
 DTYPE_FP16, DTYPE_BF16 = 0, 1
 
@@ -34,7 +35,11 @@ class DecodeArgs(ctypes.Structure):
         ("stride", ctypes.c_int), ("num_layer", ctypes.c_int), ("idx_layer", ctypes.c_int),
         ("num_splits", ctypes.c_int), ("dtype", ctypes.c_int),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("kv_layout", ctypes.c_int),
     ]
+
+
+KV_LAYOUTS = {"blmhd": 0, "blhmd": 1}      # enum sfa_kv_layout
 
 
 class PrefillArgs(ctypes.Structure):
@@ -91,8 +96,8 @@ def load():
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sfa_fill_16bit.restype = ctypes.c_int
     lib.sfa_fill_16bit.argtypes = [ctypes.c_void_p, ctypes.c_uint16, ctypes.c_size_t, ctypes.c_void_p]
-    if lib.sfa_abi_version() != 1:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.sfa_abi_version()} != 1; rebuild")
+    if lib.sfa_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.sfa_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

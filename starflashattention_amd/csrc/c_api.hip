@@ -136,6 +136,8 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= 3*H*D and a multiple of 8", stride);
     if (a->num_splits > 1024)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_splits=%d > 1024", a->num_splits);
+    if (a->kv_layout != SFA_KV_BLMHD && a->kv_layout != SFA_KV_BLHMD)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: kv_layout %d is not SFA_KV_BLMHD(0)/SFA_KV_BLHMD(1)", a->kv_layout);
     const uintptr_t align_or = (uintptr_t)a->qkv | (uintptr_t)a->o | (uintptr_t)a->k_cache_table |
                                (uintptr_t)a->v_cache_table | (uintptr_t)a->q_bias | (uintptr_t)a->k_bias |
                                (uintptr_t)a->v_bias;
@@ -179,6 +181,13 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     p.rot_dim = a->rotary_embedding_dim;
     p.num_splits = S;
     p.qkv_stride = stride;
+    if (a->kv_layout == SFA_KV_BLHMD) {
+        p.kv_row_stride = a->head_dim;
+        p.kv_head_stride = (long long)a->memory_max_len * a->head_dim;
+    } else {
+        p.kv_row_stride = hd;
+        p.kv_head_stride = a->head_dim;
+    }
     const float scale = a->head_dim_inv > 0.f ? a->head_dim_inv : 1.0f / std::sqrt((float)a->head_dim);
     p.scale_log2 = scale * 1.4426950408889634f;
     return launch_decode(p, a->dtype, a->head_dim, (hipStream_t)stream);

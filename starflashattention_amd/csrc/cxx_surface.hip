@@ -76,6 +76,7 @@ void run_flash_decoder(Flash_decoder_input &in, Flash_decoder_params &params, hi
     a.idx_layer = in.idx_layer;
     a.num_splits = params.num_splits;
     a.dtype = dtype_of<T>();
+    a.kv_layout = SFA_KV_BLMHD;         // the layout params.h documents
     const size_t need = sfa_decode_workspace_bytes(a.batch_size, a.num_heads, a.head_dim,
                                                    a.memory_max_len, a.num_splits);
     Workspace &w = workspace_for(need, stream);

@@ -6,8 +6,8 @@
 // section 8(a) rows A3-A9 for what the CUDA version intends and where it goes wrong.
 //
 // MI355X design (HBM-bound: AI = 1 FLOP/B, so the only goal is to keep HBM busy):
-//   * cache layout is the API's [B, L, M, H, D]; one (b,h) reads 2*D-byte segments at a
-//     stride of H*D*2 bytes.  D/8 lanes x 16 B cover one cache row, so one wave64
+//   * cache layout is the API's [B, L, M, H, D] (one (b,h) reads 2*D-byte segments at a
+//     stride of H*D*2 bytes) or, opt-in, head-major [B, L, H, M, D] (kv_row_stride / kv_head_stride).  D/8 lanes x 16 B cover one cache row, so one wave64
 //     global_load_dwordx4 fetches 64/(D/8) whole rows (4 rows for D=128): every 128-B line
 //     that is fetched is fully used, and neighbouring heads (blockIdx.x fastest) touch the
 //     same DRAM pages at about the same time.
@@ -171,7 +171,8 @@ decode_kernel(const DecodeKernelParams p) {
     const int w0 = min(r1, r0 + wave * per_wave);
     const int w1 = min(r1, w0 + per_wave);
 
-    const long long head_base = (((long long)b * p.L + p.layer) * p.M * p.H + h) * (long long)D + sub * 8;
+    const long long rs = p.kv_row_stride;       // elements between consecutive cache rows of this head
+    const long long head_base = ((long long)b * p.L + p.layer) * p.M * hd + h * p.kv_head_stride + sub * 8;
     const uint16_t *kb = p.k_cache + head_base;
     const uint16_t *vb = p.v_cache + head_base;
 
@@ -182,12 +183,12 @@ decode_kernel(const DecodeKernelParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);       // clamp: loads stay in range
-            kk[u] = ld16<NT>(kb + (long long)row * hd);
+            kk[u] = ld16<NT>(kb + (long long)row * rs);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);
-            vv[u] = ld16<NT>(vb + (long long)row * hd);
+            vv[u] = ld16<NT>(vb + (long long)row * rs);
         }
     };
     auto consume = [&](const uint4 (&kk)[U], const uint4 (&vv)[U], int t) {
@@ -242,7 +243,7 @@ decode_kernel(const DecodeKernelParams p) {
             for (int j = 0; j < 8; ++j) accn[j] = x[j];
             st.merge(sn, 1.0f, accn);
             // append to the caches: LPR lanes x 16 B = one row each
-            const long long roff = (long long)pos * hd;
+            const long long roff = (long long)pos * rs;
             *reinterpret_cast<uint4 *>(p.k_cache + head_base + roff) = kpk;
             *reinterpret_cast<uint4 *>(p.v_cache + head_base + roff) = vpk;
         }

@@ -28,6 +28,7 @@ struct DecodeKernelParams {
     int32_t *status;        // sticky error word
     int B, M, H, L, layer, rot_dim, num_splits;
     long long qkv_stride;   // elements between batches of qkv
+    long long kv_row_stride, kv_head_stride;    // elements between cache rows / heads of one (b, layer)
     float scale_log2;       // softmax scale * log2(e)
 };
 

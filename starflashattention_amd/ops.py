@@ -63,8 +63,9 @@ def _workspace(device, nbytes):
 def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_len, o,
                  batch_size, memory_max_len, num_heads, head_dim, rotary_embedding_dim,
                  max_input_length, num_layer, idx_layer, *, num_splits=0,
-                 rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None):
-    """One decode step (see include/star_flash_attn.h, sfa_decode).  Returns `o` (same tensor)."""
+                 rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None, kv_layout="blmhd"):
+    """One decode step (see include/star_flash_attn.h, sfa_decode).  Returns `o` (same tensor).
+    kv_layout: "blmhd" = the reference's [B, L, M, H, D] caches; "blhmd" = head-major [B, L, H, M, D]."""
     lib = _lib.load()
     _require(isinstance(qkv, torch.Tensor) and qkv.dtype in _DTYPES,
              f"qkv must be a float16 or bfloat16 tensor (got {getattr(qkv, 'dtype', type(qkv))})")
@@ -73,8 +74,10 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
     _check_gpu_tensor(qkv, "qkv", dt, (B, 3, H, D))
     _check_gpu_tensor(o, "o", dt, (B, H, D), dev)
     _check_gpu_tensor(seq_len, "seq_len", torch.int32, (B,), dev)
-    _check_gpu_tensor(k_cache_table, "k_cache_table", dt, (B, L, M, H, D), dev)
-    _check_gpu_tensor(v_cache_table, "v_cache_table", dt, (B, L, M, H, D), dev)
+    _require(kv_layout in _lib.KV_LAYOUTS, f"kv_layout must be one of {sorted(_lib.KV_LAYOUTS)} (got {kv_layout!r})")
+    cache_shape = (B, L, M, H, D) if kv_layout == "blmhd" else (B, L, H, M, D)
+    _check_gpu_tensor(k_cache_table, "k_cache_table", dt, cache_shape, dev)
+    _check_gpu_tensor(v_cache_table, "v_cache_table", dt, cache_shape, dev)
     biases = []
     for name, t in (("q_bias", q_bias), ("k_bias", k_bias), ("v_bias", v_bias)):
         if t is None or t.numel() == 0:
@@ -107,6 +110,7 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         a.dtype = _DTYPES[dt]
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
+        a.kv_layout = _lib.KV_LAYOUTS[kv_layout]
         _lib.check(lib.sfa_decode(ctypes.byref(a), _stream_ptr(dev)))
         if _sync_checks:
             check_decode_status(dev)

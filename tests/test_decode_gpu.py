@@ -254,3 +254,42 @@ def test_decode_roundtrip_multi_step_append(sfa):
     want = sdpa_ref(q, K, V)[:, :, 0]
     np.testing.assert_allclose(o.float().cpu().numpy(), want, atol=1.6e-2, rtol=1.6e-2)
     np.testing.assert_array_equal(vc[:, 0, :T].float().cpu().numpy(), V.transpose(0, 2, 1, 3))
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("num_splits", [0, 1, 3])
+def test_decode_head_major_kv_layout(sfa, dtype, num_splits):
+    """kv_layout="blhmd" (SURVEY.md 8f-2): the same decode step on [B, L, H, M, D] caches -- output
+    bit-identical to the reference layout's, the appended row lands at [b, layer, h, seq_len[b], :],
+    nothing else is touched."""
+    rng = np.random.default_rng(5)
+    B, H, D, L, M, layer = 3, 4, 128, 2, 96, 1
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    dev = torch.device("cuda:0")
+    qkv = torch.from_numpy(rng.standard_normal((B, 3, H, D)).astype(np.float32)).to(tdt).to(dev)
+    kc = torch.from_numpy(rng.standard_normal((B, L, M, H, D)).astype(np.float32)).to(tdt).to(dev)
+    vc = torch.from_numpy(rng.standard_normal((B, L, M, H, D)).astype(np.float32)).to(tdt).to(dev)
+    lens = [0, 37, M - 1]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    z = torch.zeros(0, dtype=tdt, device=dev)
+    kc_a, vc_a = kc.clone(), vc.clone()
+    kc_h, vc_h = (t.permute(0, 1, 3, 2, 4).contiguous() for t in (kc, vc))
+    o_a = torch.empty((B, H, D), dtype=tdt, device=dev)
+    o_h = torch.empty_like(o_a)
+    sfa.flash_decode(qkv, z, z, z, kc_a, vc_a, sl, o_a, B, M, H, D, D, M, L, layer, num_splits=num_splits)
+    sfa.flash_decode(qkv, z, z, z, kc_h, vc_h, sl, o_h, B, M, H, D, D, M, L, layer, num_splits=num_splits,
+                     kv_layout="blhmd")
+    torch.cuda.synchronize()
+    assert torch.equal(o_a, o_h)
+    assert torch.equal(kc_h.permute(0, 1, 3, 2, 4), kc_a)
+    assert torch.equal(vc_h.permute(0, 1, 3, 2, 4), vc_a)
+    for b in range(B):      # the appended rows really changed, everything else did not
+        assert not torch.equal(kc_a[b, layer, lens[b]], kc[b, layer, lens[b]])
+    mask = torch.ones((B, L, M), dtype=torch.bool, device=dev)
+    for b in range(B):
+        mask[b, layer, lens[b]] = False
+    assert torch.equal(kc_a[mask], kc[mask]) and torch.equal(vc_a[mask], vc[mask])
+    with pytest.raises(RuntimeError, match="kv_layout"):
+        sfa.flash_decode(qkv, z, z, z, kc_h, vc_h, sl, o_h, B, M, H, D, D, M, L, layer, kv_layout="paged")
+    with pytest.raises(RuntimeError, match="k_cache_table"):       # shape is checked against the layout
+        sfa.flash_decode(qkv, z, z, z, kc_a, vc_a, sl, o_h, B, M, H, D, D, M, L, layer, kv_layout="blhmd")

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""A/B of the decode kernel's load policy (SFA_DECODE_NT = 0 default, 1 non-temporal) at BASELINE.json configs[3]:
-B=256 Sq=1 Sk=8192 H=32 D=128 bf16.  Usage: decode_ab.py [variant ...]"""
+"""A/B of the decode kernel at BASELINE.json configs[3] (B=256 Sq=1 Sk=8192 H=32 D=128 bf16):
+load policy (SFA_DECODE_NT = 0 default, 1 non-temporal) x cache layout (LAYOUTS=blmhd,blhmd).
+Usage: [LAYOUTS=blmhd,blhmd] decode_ab.py [nt ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
 
 variants = [int(a) for a in sys.argv[1:]] or [0, 1]
+layouts = os.environ.get("LAYOUTS", "blmhd").split(",")
 B, H, Sk, D = 256, 32, 8192, 128
 dev = torch.device("cuda:0")
 kc = torch.empty((B, 1, Sk, H, D), dtype=torch.bfloat16, device=dev)
@@ -19,23 +21,23 @@ qkv = torch.randn((B, 3, H, D), device=dev).bfloat16()
 sl = torch.full((B,), Sk - 1, dtype=torch.int32, device=dev)
 z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
 nbytes = 2.0 * B * Sk * H * D * 2 + 4 * B * H * D * 2
-ref = None
 for rep in range(2):
-    for v in variants:
-        os.environ["SFA_DECODE_NT"] = str(v)
-        o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
-        run = lambda: sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, Sk, H, D, D, Sk, 1, 0)
-        for _ in range(2):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(6):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 6
-        if ref is None:
-            ref = o.clone()
-        print(f"variant {v}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s  max|diff vs first| = "
-              f"{(o.float() - ref.float()).abs().max().item():.3g}", flush=True)
+    for layout in layouts:
+        # the same bytes re-interpreted in the other layout: random data either way
+        shape = (B, 1, Sk, H, D) if layout == "blmhd" else (B, 1, H, Sk, D)
+        k, v = kc.view(shape), vc.view(shape)
+        for nt in variants:
+            os.environ["SFA_DECODE_NT"] = str(nt)
+            o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
+            run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, H, D, D, Sk, 1, 0, kv_layout=layout)
+            for _ in range(2):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(6):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 6
+            print(f"layout {layout} nt {nt}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s", flush=True)
