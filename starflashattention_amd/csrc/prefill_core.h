@@ -62,17 +62,6 @@ struct Acc {
                                 // relative to the reference max and in log2 units
 };
 
-// One pipelined half-step in explicit slot order, for all NQB query blocks of the wave:
-//   sN[q] <- scores of K rows [32*HN, +32) of the tile at kb             (DO_QK; NKS*NQB MFMAs)
-//   sO[q]  = scores of keys [32*HO, +32) of the tile whose V is at vb: row max finished (slot 0),
-//            exponentiated in place, packed to 16 bit, O^T += V^T . P^T  (NPV*NQB MFMAs)
-// kb / vb / kb_pref already include this lane's read base (Lds<D> comment).
-//   kpre[PF]  in: first PF K fragments of this half-step (read from LDS earlier);
-//             out (PREF): first PF fragments of the next half-step, rows [32*PH, +32) at kb_pref
-//   mxO[q]    in: this lane's max over the 16 scores in sO[q] (before masking)
-//   mxN[q]    out: this lane's max over the 16 new scores
-//   mask_o    bit q set: sO[q] holds keys that must be masked (diagonal / ragged tiles)
-//   PF        how many slots ahead of its MFMAs a fragment is read
 // Prescaled mode: finish the row max of freshly computed scores s (already relative to acc.msc, log2
 // units).  Lazy rescale: only when some row of the wave rose more than kRescaleThr above the reference
 // do O, the row sum, the pending scores and cinit move to the new reference (wave-uniform, rare).
@@ -83,8 +72,10 @@ __device__ __forceinline__ void finish_prescaled(f32x16 &s, Acc<D, NQB> &acc, in
         mask_half(s, kbase, h2, lim);
         mxl = lane_rowmax(s);
     }
-    const float mx = half_max(mxl);                     // both lane halves hold the same query
-    if (__any(mx > kRescaleThr)) {
+    // a row's maximum is the larger of its two lanes' maxima, so "some row rose above the threshold"
+    // needs no cross-lane exchange; the exchange happens inside the rare branch only
+    if (__any(mxl > kRescaleThr)) {
+        const float mx = half_max(mxl);                 // both lane halves hold the same query
         const float d = fmaxf(mx, 0.f);                 // rows that did not rise keep their reference
         const float alpha = fast_exp2(-d);
         acc.msc[q] += d;
@@ -98,6 +89,17 @@ __device__ __forceinline__ void finish_prescaled(f32x16 &s, Acc<D, NQB> &acc, in
     }
 }
 
+// One pipelined half-step in explicit slot order, for all NQB query blocks of the wave:
+//   sN[q] <- scores of K rows [32*HN, +32) of the tile at kb             (DO_QK; NKS*NQB MFMAs)
+//   sO[q]  = scores of keys [32*HO, +32) of the tile whose V is at vb: row max finished (slot 0),
+//            exponentiated in place, packed to 16 bit, O^T += V^T . P^T  (NPV*NQB MFMAs)
+// kb / vb / kb_pref already include this lane's read base (Lds<D> comment).
+//   kpre[PF]  in: first PF K fragments of this half-step (read from LDS earlier);
+//             out (PREF): first PF fragments of the next half-step, rows [32*PH, +32) at kb_pref
+//   mxO[q]    in: this lane's max over the 16 scores in sO[q] (before masking)
+//   mxN[q]    out: this lane's max over the 16 new scores
+//   mask_o    bit q set: sO[q] holds keys that must be masked (diagonal / ragged tiles)
+//   PF        how many slots ahead of its MFMAs a fragment is read
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
 template <class Tr, int D, int NQB, int PF, int ORD, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook, class PvHook = NoHook, int PH = 1 - HN>
@@ -163,8 +165,9 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
             mask_half(sO[q], kbase_o, h2, lim[q]);
             mxl = lane_rowmax(sO[q]);
         }
-        const float mx = half_max(mxl) * c2;            // both lane halves hold the same query
-        if (__any(mx > acc.msc[q] + kRescaleThr)) {     // rare after the first tiles
+        // (a row's two lanes share msc, so the trigger needs no cross-lane exchange)
+        if (__any(mxl * c2 > acc.msc[q] + kRescaleThr)) {       // rare after the first tiles
+            const float mx = half_max(mxl) * c2;        // both lane halves hold the same query
             const float mnew = fmaxf(acc.msc[q], mx);
             const float alpha = (mnew == ninf()) ? 1.0f : fast_exp2(acc.msc[q] - mnew);
             acc.msc[q] = mnew;
