@@ -42,8 +42,10 @@ typedef enum sfa_status {
     SFA_ERR_UNSUPPORTED_HEAD_DIM = -4,
     SFA_ERR_WORKSPACE_TOO_SMALL = -5,
     SFA_ERR_LAUNCH = -6,         /* HIP reported a launch/runtime failure            */
-    SFA_ERR_SEQ_LEN_RANGE = -7   /* reported by sfa_decode_poll_status: some
+    SFA_ERR_SEQ_LEN_RANGE = -7,  /* reported by sfa_decode_poll_status: some
                                     seq_len[b] was outside [0, memory_max_len)       */
+    SFA_ERR_BLOCK_TABLE_RANGE = -8 /* reported by sfa_decode_poll_status: a block_table
+                                    entry was outside [0, num_pages); page 0 was read instead */
 } sfa_status;
 
 typedef enum sfa_dtype {
@@ -58,7 +60,13 @@ typedef enum sfa_dtype {
  * so one (b,h) streams a dense 2*M*D-byte region instead of 2*D-byte segments H*D*2 bytes apart. */
 typedef enum sfa_kv_layout {
     SFA_KV_BLMHD = 0,            /* [batch, num_layer, memory_max_len, num_heads, head_dim] */
-    SFA_KV_BLHMD = 1             /* [batch, num_layer, num_heads, memory_max_len, head_dim] */
+    SFA_KV_BLHMD = 1,            /* [batch, num_layer, num_heads, memory_max_len, head_dim] */
+    SFA_KV_PAGED = 2             /* page pools [num_pages, num_layer, page_size, num_heads, head_dim]
+                                    addressed through block_table (the reference only NAMES its
+                                    cache pointers k_cache_table / v_cache_table, src/params.h:22-25):
+                                    token t of sequence b lives in page block_table[b][t / page_size],
+                                    row t % page_size.  memory_max_len = the capacity of one sequence
+                                    (<= block_table_stride * page_size).                            */
 } sfa_kv_layout;
 
 /* ---- library ------------------------------------------------------------------ */
@@ -114,6 +122,11 @@ typedef struct sfa_decode_args {
     void *workspace;                /* >= sfa_decode_workspace_bytes(...), 256-B aligned */
     size_t workspace_bytes;
     int kv_layout;                  /* sfa_kv_layout; 0 = the reference's layout (ABI v2) */
+    /* -- SFA_KV_PAGED only -- */
+    int page_size;                  /* tokens per page: a power of two >= 16             */
+    const void *block_table;        /* int32 [batch, block_table_stride] page numbers    */
+    int block_table_stride;         /* entries per sequence, >= ceil(memory_max_len / page_size) */
+    int num_pages;                  /* pages in each pool (bounds the table entries)     */
 } sfa_decode_args;
 
 /* Bytes of scratch sfa_decode needs for this shape (num_splits <= 0: the library's choice
@@ -125,7 +138,8 @@ size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim,
 int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len);
 /* Zero the sticky status word (async). Call once after allocating a workspace. */
 int sfa_decode_reset_status(void *workspace, void *stream);
-/* Synchronises `stream`, reads the status word: SFA_OK or SFA_ERR_SEQ_LEN_RANGE. */
+/* Synchronises `stream`, reads the status word: SFA_OK, SFA_ERR_SEQ_LEN_RANGE or
+ * SFA_ERR_BLOCK_TABLE_RANGE. */
 int sfa_decode_poll_status(const void *workspace, void *stream);
 int sfa_decode(const sfa_decode_args *args, void *stream);
 

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libStarFlashAttention.so")
 SFA_OK = 0
 ABI_VERSION = 2          # SFA_ABI_VERSION in include/star_flash_attn.h
 SFA_ERR_SEQ_LEN_RANGE = -7
+SFA_ERR_BLOCK_TABLE_RANGE = -8
 DTYPE_FP16, DTYPE_BF16 = 0, 1
 
 # every symbol include/star_flash_attn.h declares (tests check the .so exports all of them)
@@ -35,11 +36,12 @@ class DecodeArgs(ctypes.Structure):
         ("stride", ctypes.c_int), ("num_layer", ctypes.c_int), ("idx_layer", ctypes.c_int),
         ("num_splits", ctypes.c_int), ("dtype", ctypes.c_int),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
-        ("kv_layout", ctypes.c_int),
+        ("kv_layout", ctypes.c_int), ("page_size", ctypes.c_int), ("block_table", ctypes.c_void_p),
+        ("block_table_stride", ctypes.c_int), ("num_pages", ctypes.c_int),
     ]
 
 
-KV_LAYOUTS = {"blmhd": 0, "blhmd": 1}      # enum sfa_kv_layout
+KV_LAYOUTS = {"blmhd": 0, "blhmd": 1, "paged": 2}      # enum sfa_kv_layout
 
 
 class PrefillArgs(ctypes.Structure):

@@ -68,6 +68,7 @@ const char *sfa_status_string(int status) {
         case SFA_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
         case SFA_ERR_LAUNCH: return "HIP launch failure";
         case SFA_ERR_SEQ_LEN_RANGE: return "seq_len out of range";
+        case SFA_ERR_BLOCK_TABLE_RANGE: return "block_table entry out of range";
         default: return "unknown status";
     }
 }
@@ -105,6 +106,9 @@ int sfa_decode_poll_status(const void *workspace, void *stream) {
     hipError_t e = hipMemcpyAsync(&word, workspace, sizeof(word), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return fail(SFA_ERR_LAUNCH, "sfa_decode_poll_status: %s", hipGetErrorString(e));
+    if (word & 2)
+        return fail(SFA_ERR_BLOCK_TABLE_RANGE,
+                    "sfa_decode: a block_table entry was outside [0, num_pages); page 0 was used in its place");
     if (word != 0)
         return fail(SFA_ERR_SEQ_LEN_RANGE,
                     "sfa_decode: some seq_len[b] was outside [0, memory_max_len); those outputs are NaN "
@@ -136,8 +140,22 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= 3*H*D and a multiple of 8", stride);
     if (a->num_splits > 1024)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_splits=%d > 1024", a->num_splits);
-    if (a->kv_layout != SFA_KV_BLMHD && a->kv_layout != SFA_KV_BLHMD)
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: kv_layout %d is not SFA_KV_BLMHD(0)/SFA_KV_BLHMD(1)", a->kv_layout);
+    if (a->kv_layout != SFA_KV_BLMHD && a->kv_layout != SFA_KV_BLHMD && a->kv_layout != SFA_KV_PAGED)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: kv_layout %d is not SFA_KV_BLMHD(0)/SFA_KV_BLHMD(1)/SFA_KV_PAGED(2)",
+                    a->kv_layout);
+    int page_shift = 0;
+    if (a->kv_layout == SFA_KV_PAGED) {
+        if (!a->block_table) return fail(SFA_ERR_NULL_POINTER, "sfa_decode: kv_layout PAGED needs block_table");
+        if (a->page_size < 16 || (a->page_size & (a->page_size - 1)))
+            return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: page_size=%d must be a power of two >= 16", a->page_size);
+        while ((1 << page_shift) < a->page_size) ++page_shift;
+        if (a->num_pages <= 0 ||
+            (long long)a->block_table_stride * a->page_size < (long long)a->memory_max_len)
+            return fail(SFA_ERR_BAD_SHAPE,
+                        "sfa_decode: num_pages=%d, block_table_stride=%d * page_size=%d must cover memory_max_len=%d",
+                        a->num_pages, a->block_table_stride, a->page_size, a->memory_max_len);
+        if ((uintptr_t)a->block_table & 3) return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: block_table must be 4-byte aligned");
+    }
     const uintptr_t align_or = (uintptr_t)a->qkv | (uintptr_t)a->o | (uintptr_t)a->k_cache_table |
                                (uintptr_t)a->v_cache_table | (uintptr_t)a->q_bias | (uintptr_t)a->k_bias |
                                (uintptr_t)a->v_bias;
@@ -181,7 +199,15 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     p.rot_dim = a->rotary_embedding_dim;
     p.num_splits = S;
     p.qkv_stride = stride;
-    if (a->kv_layout == SFA_KV_BLHMD) {
+    if (a->kv_layout == SFA_KV_PAGED) {
+        p.kv_row_stride = hd;                   // rows of a page are [page_size, H, D]
+        p.kv_head_stride = a->head_dim;
+        p.block_table = (const int32_t *)a->block_table;
+        p.page_shift = page_shift;
+        p.table_stride = a->block_table_stride;
+        p.num_pages = a->num_pages;
+        p.page_stride = (long long)a->num_layer * a->page_size * hd;
+    } else if (a->kv_layout == SFA_KV_BLHMD) {
         p.kv_row_stride = a->head_dim;
         p.kv_head_stride = (long long)a->memory_max_len * a->head_dim;
     } else {

@@ -89,7 +89,7 @@ struct Stream {
     }
 };
 
-template <class Tr, int D, int U, bool NT, int W = kDecodeWaves>
+template <class Tr, int D, int U, bool NT, bool PAGED = false, int W = kDecodeWaves>
 __global__ void __launch_bounds__(W * 64)
 decode_kernel(const DecodeKernelParams p) {
     constexpr int LPR = D / 8;          // lanes per cache row
@@ -168,27 +168,56 @@ decode_kernel(const DecodeKernelParams p) {
     const int r1 = min(pos, r0 + rows_per_split);
     int per_wave = (r1 - r0 + W - 1) / W;
     per_wave = (per_wave + STEP - 1) / STEP * STEP;
-    const int w0 = min(r1, r0 + wave * per_wave);
-    const int w1 = min(r1, w0 + per_wave);
+    // (readfirstlane: wave-uniform by construction, and the paged path wants scalar table loads)
+    const int w0 = __builtin_amdgcn_readfirstlane(min(r1, r0 + wave * per_wave));
+    const int w1 = __builtin_amdgcn_readfirstlane(min(r1, w0 + per_wave));
 
     const long long rs = p.kv_row_stride;       // elements between consecutive cache rows of this head
-    const long long head_base = ((long long)b * p.L + p.layer) * p.M * hd + h * p.kv_head_stride + sub * 8;
+    // contiguous layouts: rows of this (b, layer, h) start at head_base, rs apart.
+    // paged: row r lives in page table[r >> page_shift] of the pool, at row r & (page_size-1).
+    const long long head_base = PAGED ? (long long)p.layer * (rs << p.page_shift) + (long long)h * p.kv_head_stride + sub * 8
+                                      : ((long long)b * p.L + p.layer) * p.M * hd + h * p.kv_head_stride + sub * 8;
     const uint16_t *kb = p.k_cache + head_base;
     const uint16_t *vb = p.v_cache + head_base;
+    const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;   // uniform
+    const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    auto page_of = [&](int idx) -> int {        // scalar: table entry, clamped into the pool
+        int pg = tbl[idx];
+        if ((unsigned)pg >= (unsigned)p.num_pages) {
+            if (tid == 0) atomicOr(p.status, 2);        // sticky: a block_table entry outside the pool
+            pg = 0;
+        }
+        return pg;
+    };
 
     Stream st;
     st.init();
 
+    // A step covers STEP <= 16 consecutive rows starting at the wave-uniform t: with page_size >= 16 they
+    // touch at most two pages, looked up with two SCALAR loads (no vmcnt ordering against the
+    // in-flight K/V loads) and selected per lane.
+    auto row_off = [&](int row, int i0, long long o0, long long o1) -> long long {
+        if (!PAGED) return (long long)row * rs;
+        return ((row >> p.page_shift) == i0 ? o0 : o1) + (long long)(row & pmask) * rs;
+    };
     auto load = [&](uint4 (&kk)[U], uint4 (&vv)[U], int t) {
+        int i0 = 0;
+        long long o0 = 0, o1 = 0;
+        if (PAGED) {
+            i0 = t >> p.page_shift;
+            const int i1 = min(i0 + 1, (w1 - 1) >> p.page_shift);
+            o0 = page_of(i0) * p.page_stride;
+            o1 = page_of(i1) * p.page_stride;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);       // clamp: loads stay in range
-            kk[u] = ld16<NT>(kb + (long long)row * rs);
+            kk[u] = ld16<NT>(kb + row_off(row, i0, o0, o1));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * G + grp, w1 - 1);
-            vv[u] = ld16<NT>(vb + (long long)row * rs);
+            vv[u] = ld16<NT>(vb + row_off(row, i0, o0, o1));
         }
     };
     auto consume = [&](const uint4 (&kk)[U], const uint4 (&vv)[U], int t) {
@@ -243,7 +272,8 @@ decode_kernel(const DecodeKernelParams p) {
             for (int j = 0; j < 8; ++j) accn[j] = x[j];
             st.merge(sn, 1.0f, accn);
             // append to the caches: LPR lanes x 16 B = one row each
-            const long long roff = (long long)pos * rs;
+            long long roff = (long long)pos * rs;
+            if (PAGED) roff = page_of(pos >> p.page_shift) * p.page_stride + (long long)(pos & pmask) * rs;
             *reinterpret_cast<uint4 *>(p.k_cache + head_base + roff) = kpk;
             *reinterpret_cast<uint4 *>(p.v_cache + head_base + roff) = vpk;
         }
@@ -333,8 +363,14 @@ int launch_decode_t(const DecodeKernelParams &p, hipStream_t stream) {
     // and is re-read from the Infinity Cache / L2.  SFA_DECODE_NT=0/1 overrides (tests, A/B).
     bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
     if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
-    if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, 4, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((decode_kernel<Tr, D, 4, false>), grid, block, 0, stream, p);
+    if (p.block_table) {
+        constexpr int UP = 16 / (64 / (D / 8));     // a step = 16 rows: at most two pages (page_size >= 16)
+        if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, UP, true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((decode_kernel<Tr, D, UP, false, true>), grid, block, 0, stream, p);
+    } else {
+        if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, 4, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((decode_kernel<Tr, D, 4, false>), grid, block, 0, stream, p);
+    }
     int rc = check_launch("decode_kernel");
     if (rc != SFA_OK) return rc;
     if (p.num_splits > 1) {

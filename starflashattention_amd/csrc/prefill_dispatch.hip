@@ -1,8 +1,7 @@
 // Picks the prefill kernel.
 //   auto (default): the 256-row software-pipelined kernel (prefill_kernel.hip) whenever the problem
-//     has at least one of its workgroups (a pair of 256-row q-tiles) per CU; smaller problems take the 128-row geometry
-//     (prefill_kernel_bm128.hip: twice the workgroups, measured 5-14 % faster when the 256-row grid
-//     cannot fill the 256 CUs and 7-10 % slower when it can).
+//     has enough of its workgroups (a pair of 256-row q-tiles each) for about half the 256 CUs; smaller
+//     problems take the 128-row geometry (prefill_kernel_bm128.hip: four times the workgroups).
 //     Each geometry comes in two numeric flavours: exact scale (scores = fp32 QK^T times the scale in
 //     fp32) and prescaled Q (Q * scale * log2 e rounded to 16 bit once per q-tile, the scale pass
 //     gone from the inner loop: +5 %).  Calls that return the log-sum-exp get the exact flavour,
@@ -24,9 +23,11 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     const char *e = std::getenv("SFA_PREFILL_IMPL_DYNAMIC");      // tests / A-B harness: re-read every call
     int which = e ? std::atoi(e) : impl;
     if (which < 0) {
-        // the 256-row kernel runs one workgroup per PAIR of q-tiles
+        // the 256-row kernel runs one workgroup per PAIR of q-tiles.  Measured crossover
+        // (tools/prefill_small_grids.sh): causal, 64 pair-workgroups 128-row +18..39 %, 128: -10..+7 %,
+        // 192+: 256-row +15 %; full attention (pairing balances nothing there), 128: 128-row +39 %, 192: -3 %
         const long long wgs = (long long)p.B * p.Hq * (((p.Sq + 255) / 256 + 1) / 2);
-        which = wgs < 256 ? 20 : 1;
+        which = wgs < (causal ? 128 : 192) ? 20 : 1;
     }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
     if (which >= 30 && which <= 32) return launch_prefill_x16(p, dtype, head_dim, causal, stream, which - 30);

@@ -29,6 +29,9 @@ struct DecodeKernelParams {
     int B, M, H, L, layer, rot_dim, num_splits;
     long long qkv_stride;   // elements between batches of qkv
     long long kv_row_stride, kv_head_stride;    // elements between cache rows / heads of one (b, layer)
+    const int32_t *block_table;  // paged caches: [B, table_stride] page numbers, else nullptr
+    int page_shift, table_stride, num_pages;    // page_size = 1 << page_shift
+    long long page_stride;       // elements between pages of a pool
     float scale_log2;       // softmax scale * log2(e)
 };
 

@@ -63,9 +63,12 @@ def _workspace(device, nbytes):
 def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_len, o,
                  batch_size, memory_max_len, num_heads, head_dim, rotary_embedding_dim,
                  max_input_length, num_layer, idx_layer, *, num_splits=0,
-                 rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None, kv_layout="blmhd"):
+                 rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None, kv_layout="blmhd",
+                 block_table=None):
     """One decode step (see include/star_flash_attn.h, sfa_decode).  Returns `o` (same tensor).
-    kv_layout: "blmhd" = the reference's [B, L, M, H, D] caches; "blhmd" = head-major [B, L, H, M, D]."""
+    kv_layout: "blmhd" = the reference's [B, L, M, H, D] caches; "blhmd" = head-major [B, L, H, M, D];
+    "paged" = page pools [num_pages, L, page_size, H, D] addressed through block_table (int32
+    [B, pages_per_seq]); memory_max_len is then the capacity of one sequence."""
     lib = _lib.load()
     _require(isinstance(qkv, torch.Tensor) and qkv.dtype in _DTYPES,
              f"qkv must be a float16 or bfloat16 tensor (got {getattr(qkv, 'dtype', type(qkv))})")
@@ -75,7 +78,17 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
     _check_gpu_tensor(o, "o", dt, (B, H, D), dev)
     _check_gpu_tensor(seq_len, "seq_len", torch.int32, (B,), dev)
     _require(kv_layout in _lib.KV_LAYOUTS, f"kv_layout must be one of {sorted(_lib.KV_LAYOUTS)} (got {kv_layout!r})")
-    cache_shape = (B, L, M, H, D) if kv_layout == "blmhd" else (B, L, H, M, D)
+    if kv_layout == "paged":
+        _require(isinstance(block_table, torch.Tensor) and block_table.dim() == 2,
+                 "kv_layout='paged' needs block_table, an int32 [batch, pages_per_seq] tensor")
+        _require(isinstance(k_cache_table, torch.Tensor) and k_cache_table.dim() == 5,
+                 "k_cache_table must be a [num_pages, num_layer, page_size, num_heads, head_dim] pool")
+        num_pages, page_size = int(k_cache_table.shape[0]), int(k_cache_table.shape[2])
+        cache_shape = (num_pages, L, page_size, H, D)
+        _check_gpu_tensor(block_table, "block_table", torch.int32, (B, int(block_table.shape[1])), dev)
+    else:
+        _require(block_table is None, "block_table is only meaningful with kv_layout='paged'")
+        cache_shape = (B, L, M, H, D) if kv_layout == "blmhd" else (B, L, H, M, D)
     _check_gpu_tensor(k_cache_table, "k_cache_table", dt, cache_shape, dev)
     _check_gpu_tensor(v_cache_table, "v_cache_table", dt, cache_shape, dev)
     biases = []
@@ -111,6 +124,10 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
         a.kv_layout = _lib.KV_LAYOUTS[kv_layout]
+        if kv_layout == "paged":
+            a.page_size, a.num_pages = page_size, num_pages
+            a.block_table = block_table.data_ptr()
+            a.block_table_stride = int(block_table.shape[1])
         _lib.check(lib.sfa_decode(ctypes.byref(a), _stream_ptr(dev)))
         if _sync_checks:
             check_decode_status(dev)

@@ -293,3 +293,61 @@ def test_decode_head_major_kv_layout(sfa, dtype, num_splits):
         sfa.flash_decode(qkv, z, z, z, kc_h, vc_h, sl, o_h, B, M, H, D, D, M, L, layer, kv_layout="paged")
     with pytest.raises(RuntimeError, match="k_cache_table"):       # shape is checked against the layout
         sfa.flash_decode(qkv, z, z, z, kc_a, vc_a, sl, o_h, B, M, H, D, D, M, L, layer, kv_layout="blhmd")
+
+
+@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64)])
+@pytest.mark.parametrize("num_splits", [0, 1, 3])
+@pytest.mark.parametrize("page_size", [16, 64])
+def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
+    """kv_layout="paged" (SURVEY.md 8f-2): the contiguous caches cut into pages and scattered through
+    a shuffled pool.  Output bit-identical to the contiguous run; the new row lands in the right page;
+    no other pool byte changes; a table entry outside the pool raises the sticky status."""
+    rng = np.random.default_rng(7)
+    B, H, L, M, layer = 3, 4, 2, 192, 1
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    dev = torch.device("cuda:0")
+    qkv = torch.from_numpy(rng.standard_normal((B, 3, H, D)).astype(np.float32)).to(tdt).to(dev)
+    kc = torch.from_numpy(rng.standard_normal((B, L, M, H, D)).astype(np.float32)).to(tdt).to(dev)
+    vc = torch.from_numpy(rng.standard_normal((B, L, M, H, D)).astype(np.float32)).to(tdt).to(dev)
+    lens = [0, 77, M - 1]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    z = torch.zeros(0, dtype=tdt, device=dev)
+    pps = M // page_size                                   # pages per sequence
+    num_pages = B * pps + 5                                 # a few pages nobody owns
+    perm = torch.from_numpy(rng.permutation(num_pages)[:B * pps].astype(np.int32)).view(B, pps)
+    table = perm.to(dev)
+
+    def to_pool(c):
+        pool = torch.from_numpy(rng.standard_normal((num_pages, L, page_size, H, D)).astype(np.float32)).to(tdt).to(dev)
+        # [B, L, pps, page_size, H, D] -> pool[table[b, i]] = c[b, :, i*ps:(i+1)*ps]
+        pool[table.long().view(-1)] = c.view(B, L, pps, page_size, H, D).permute(0, 2, 1, 3, 4, 5).reshape(
+            B * pps, L, page_size, H, D)
+        return pool
+    kp, vp = to_pool(kc), to_pool(vc)
+    kp0, vp0 = kp.clone(), vp.clone()
+    kc_a, vc_a = kc.clone(), vc.clone()
+    o_a = torch.empty((B, H, D), dtype=tdt, device=dev)
+    o_p = torch.empty_like(o_a)
+    sfa.flash_decode(qkv, z, z, z, kc_a, vc_a, sl, o_a, B, M, H, D, D, M, L, layer, num_splits=num_splits)
+    sfa.flash_decode(qkv, z, z, z, kp, vp, sl, o_p, B, M, H, D, D, M, L, layer, num_splits=num_splits,
+                     kv_layout="paged", block_table=table)
+    sfa.check_decode_status()
+    assert torch.equal(o_a, o_p)
+    changed_k = (kp != kp0).flatten(2).any(-1)             # [num_pages, L]
+    for b in range(B):
+        pg, row = int(perm[b, lens[b] // page_size]), lens[b] % page_size
+        assert torch.equal(kp[pg, layer, row], kc_a[b, layer, lens[b]])
+        assert torch.equal(vp[pg, layer, row], vc_a[b, layer, lens[b]])
+        kp0[pg, layer, row] = kp[pg, layer, row]
+        vp0[pg, layer, row] = vp[pg, layer, row]
+    assert torch.equal(kp, kp0) and torch.equal(vp, vp0)   # nothing but the three appended rows changed
+    assert int(changed_k.sum()) == B
+    # a table entry outside the pool: reported, not dereferenced
+    bad = table.clone()
+    bad[1, 0] = num_pages + 3
+    sfa.flash_decode(qkv, z, z, z, kp, vp, sl, o_p, B, M, H, D, D, M, L, layer, kv_layout="paged", block_table=bad)
+    with pytest.raises(RuntimeError, match="block_table"):
+        sfa.check_decode_status()
+    with pytest.raises(RuntimeError, match="page_size"):
+        sfa.flash_decode(qkv, z, z, z, kp[:, :, :8].contiguous(), vp[:, :, :8].contiguous(), sl, o_p, B, M, H, D, D,
+                         M, L, layer, kv_layout="paged", block_table=table)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the decode kernel at BASELINE.json configs[3] (B=256 Sq=1 Sk=8192 H=32 D=128 bf16):
-load policy (SFA_DECODE_NT = 0 default, 1 non-temporal) x cache layout (LAYOUTS=blmhd,blhmd).
+load policy (SFA_DECODE_NT = 0 default, 1 non-temporal) x cache layout (LAYOUTS=blmhd,blhmd,paged:16).
 Usage: [LAYOUTS=blmhd,blhmd] decode_ab.py [nt ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,12 +24,18 @@ nbytes = 2.0 * B * Sk * H * D * 2 + 4 * B * H * D * 2
 for rep in range(2):
     for layout in layouts:
         # the same bytes re-interpreted in the other layout: random data either way
-        shape = (B, 1, Sk, H, D) if layout == "blmhd" else (B, 1, H, Sk, D)
+        kw = {"kv_layout": layout.split(":")[0]}
+        if layout.startswith("paged"):          # paged:PS -- pool of B*Sk/PS pages, randomly assigned
+            ps = int(layout.split(":")[1])
+            shape = (B * Sk // ps, 1, ps, H, D)
+            kw["block_table"] = torch.randperm(B * Sk // ps, device=dev).to(torch.int32).view(B, Sk // ps)
+        else:
+            shape = (B, 1, Sk, H, D) if layout == "blmhd" else (B, 1, H, Sk, D)
         k, v = kc.view(shape), vc.view(shape)
         for nt in variants:
             os.environ["SFA_DECODE_NT"] = str(nt)
             o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
-            run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, H, D, D, Sk, 1, 0, kv_layout=layout)
+            run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, H, D, D, Sk, 1, 0, **kw)
             for _ in range(2):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
