@@ -37,7 +37,7 @@ class DecodeArgs(ctypes.Structure):
         ("num_splits", ctypes.c_int), ("dtype", ctypes.c_int),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("kv_layout", ctypes.c_int), ("page_size", ctypes.c_int), ("block_table", ctypes.c_void_p),
-        ("block_table_stride", ctypes.c_int), ("num_pages", ctypes.c_int),
+        ("block_table_stride", ctypes.c_int), ("num_pages", ctypes.c_int), ("num_heads_kv", ctypes.c_int),
     ]
 
 

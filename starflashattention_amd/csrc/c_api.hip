@@ -134,10 +134,18 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
                     a->rotary_embedding_dim);
     if (a->dtype != SFA_DTYPE_FP16 && a->dtype != SFA_DTYPE_BF16)
         return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", a->dtype);
-    const long long hd = (long long)a->num_heads * a->head_dim;
-    const long long stride = a->stride > 0 ? a->stride : 3 * hd;
-    if (stride < 3 * hd || (stride % 8) != 0)
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= 3*H*D and a multiple of 8", stride);
+    const int hkv = a->num_heads_kv > 0 ? a->num_heads_kv : a->num_heads;
+    const int group = hkv > 0 ? a->num_heads / hkv : 0;
+    if (a->num_heads_kv < 0 || group * hkv != a->num_heads || (group != 1 && group != 2 && group != 4 && group != 8))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_heads=%d / num_heads_kv=%d must be 1, 2, 4 or 8",
+                    a->num_heads, a->num_heads_kv);
+    const long long hd = (long long)hkv * a->head_dim;          // elements per cache row
+    const long long row = (long long)(a->num_heads + 2 * hkv) * a->head_dim;    // packed q,k,v of one token
+    const long long stride = a->stride > 0 ? a->stride : row;
+    if (stride < row || (stride % 8) != 0)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= (H + 2*Hkv)*D and a multiple of 8", stride);
+    if (group != 1 && a->kv_layout == SFA_KV_PAGED)
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: paged caches with num_heads_kv != num_heads are not supported");
     if (a->num_splits > 1024)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_splits=%d > 1024", a->num_splits);
     if (a->kv_layout != SFA_KV_BLMHD && a->kv_layout != SFA_KV_BLHMD && a->kv_layout != SFA_KV_PAGED)
@@ -194,6 +202,7 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     p.B = a->batch_size;
     p.M = a->memory_max_len;
     p.H = a->num_heads;
+    p.Hkv = hkv;
     p.L = a->num_layer;
     p.layer = a->idx_layer;
     p.rot_dim = a->rotary_embedding_dim;

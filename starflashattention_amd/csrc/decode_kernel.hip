@@ -24,70 +24,13 @@
 //     k_rot / v_new from registers, adds them to its softmax stream and writes the cache row.
 #include <cstdlib>
 
-#include "sfa_device.h"
-#include "sfa_host.h"
+#include "decode_common.h"
 
 namespace sfa {
 
 namespace {
 
-constexpr int kDecodeWaves = 4;
-
-__device__ __forceinline__ float neg_inf() { return -__builtin_huge_valf(); }
-
-template <class Tr>
-__device__ __forceinline__ float dot8(const uint4 &a, const uint4 &b) {
-    float s = Tr::dot2(a.x, b.x, 0.0f);
-    s = Tr::dot2(a.y, b.y, s);
-    s = Tr::dot2(a.z, b.z, s);
-    s = Tr::dot2(a.w, b.w, s);
-    return s;
-}
-
-template <class Tr>
-__device__ __forceinline__ void unpack8(const uint4 &v, float (&x)[8]) {
-    x[0] = Tr::lo_f32(v.x); x[1] = Tr::hi_f32(v.x);
-    x[2] = Tr::lo_f32(v.y); x[3] = Tr::hi_f32(v.y);
-    x[4] = Tr::lo_f32(v.z); x[5] = Tr::hi_f32(v.z);
-    x[6] = Tr::lo_f32(v.w); x[7] = Tr::hi_f32(v.w);
-}
-
-template <class Tr>
-__device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
-    return make_uint4(Tr::pack2(x[0], x[1]), Tr::pack2(x[2], x[3]),
-                      Tr::pack2(x[4], x[5]), Tr::pack2(x[6], x[7]));
-}
-
-// 16-byte cache-row load; NT = non-temporal (the cache rows are read exactly once per step)
-template <bool NT>
-__device__ __forceinline__ uint4 ld16(const uint16_t *p) {
-    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    if (NT) {
-        const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(p));
-        return make_uint4(v[0], v[1], v[2], v[3]);
-    }
-    return *reinterpret_cast<const uint4 *>(p);
-}
-
-// Running softmax state of one lane group: max (log2 units), sum, and this lane's 8 output dims.
-struct Stream {
-    float m, l, acc[8];
-    __device__ __forceinline__ void init() {
-        m = neg_inf(); l = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    }
-    // fold another stream (m2, l2, acc2) into this one
-    __device__ __forceinline__ void merge(float m2, float l2, const float (&acc2)[8]) {
-        const float mn = fmaxf(m, m2);
-        const float ms = (mn == neg_inf()) ? 0.f : mn;
-        const float a1 = fast_exp2(m - ms), a2 = fast_exp2(m2 - ms);
-        l = l * a1 + l2 * a2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a1 + acc2[j] * a2;
-        m = mn;
-    }
-};
+using namespace decode;
 
 template <class Tr, int D, int U, bool NT, bool PAGED = false, int W = kDecodeWaves>
 __global__ void __launch_bounds__(W * 64)
@@ -355,23 +298,30 @@ decode_combine_kernel(const DecodeKernelParams p) {
 }
 
 template <class Tr, int D>
-int launch_decode_t(const DecodeKernelParams &p, hipStream_t stream) {
-    dim3 grid(p.H, p.num_splits, p.B), block(kDecodeWaves * 64);
-    // The cache rows are read exactly once per call.  When the two caches together do not fit the
-    // 256 MB Infinity Cache nothing of them survives until the next token's call either, so they are
-    // loaded non-temporally (config 4: 6.30 -> 6.51 TB/s); a small cache keeps the default policy
-    // and is re-read from the Infinity Cache / L2.  SFA_DECODE_NT=0/1 overrides (tests, A/B).
-    bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
-    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
-    if (p.block_table) {
-        constexpr int UP = 16 / (64 / (D / 8));     // a step = 16 rows: at most two pages (page_size >= 16)
-        if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, UP, true, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((decode_kernel<Tr, D, UP, false, true>), grid, block, 0, stream, p);
+int launch_decode_t(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
+    int rc;
+    if (p.Hkv != p.H) {
+        // grouped queries: one workgroup per (batch, kv head, split) serves the whole group
+        if (p.block_table) return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: paged caches with num_heads_kv != num_heads are not supported");
+        rc = launch_decode_gqa(p, dtype, D, stream);
     } else {
-        if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, 4, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((decode_kernel<Tr, D, 4, false>), grid, block, 0, stream, p);
+        dim3 grid(p.H, p.num_splits, p.B), block(kDecodeWaves * 64);
+        // The cache rows are read exactly once per call.  When the two caches together do not fit the
+        // 256 MB Infinity Cache nothing of them survives until the next token's call either, so they are
+        // loaded non-temporally (config 4: 6.30 -> 6.51 TB/s); a small cache keeps the default policy
+        // and is re-read from the Infinity Cache / L2.  SFA_DECODE_NT=0/1 overrides (tests, A/B).
+        bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
+        if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+        if (p.block_table) {
+            constexpr int UP = 16 / (64 / (D / 8));     // a step = 16 rows: at most two pages (page_size >= 16)
+            if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, UP, true, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((decode_kernel<Tr, D, UP, false, true>), grid, block, 0, stream, p);
+        } else {
+            if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, 4, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((decode_kernel<Tr, D, 4, false>), grid, block, 0, stream, p);
+        }
+        rc = check_launch("decode_kernel");
     }
-    int rc = check_launch("decode_kernel");
     if (rc != SFA_OK) return rc;
     if (p.num_splits > 1) {
         const long long threads = (long long)p.B * p.H * (D / 8);
@@ -386,11 +336,11 @@ int launch_decode_t(const DecodeKernelParams &p, hipStream_t stream) {
 
 int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
-        if (head_dim == 128) return launch_decode_t<Fp16, 128>(p, stream);
-        if (head_dim == 64) return launch_decode_t<Fp16, 64>(p, stream);
+        if (head_dim == 128) return launch_decode_t<Fp16, 128>(p, dtype, stream);
+        if (head_dim == 64) return launch_decode_t<Fp16, 64>(p, dtype, stream);
     } else if (dtype == SFA_DTYPE_BF16) {
-        if (head_dim == 128) return launch_decode_t<Bf16, 128>(p, stream);
-        if (head_dim == 64) return launch_decode_t<Bf16, 64>(p, stream);
+        if (head_dim == 128) return launch_decode_t<Bf16, 128>(p, dtype, stream);
+        if (head_dim == 64) return launch_decode_t<Bf16, 64>(p, dtype, stream);
     } else {
         return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", dtype);
     }

@@ -27,6 +27,7 @@ struct DecodeKernelParams {
     float2 *part_ml;        // [B,H,S]     (running max in log2 units, running sum)
     int32_t *status;        // sticky error word
     int B, M, H, L, layer, rot_dim, num_splits;
+    int Hkv;                // kv heads (== H unless grouped queries)
     long long qkv_stride;   // elements between batches of qkv
     long long kv_row_stride, kv_head_stride;    // elements between cache rows / heads of one (b, layer)
     const int32_t *block_table;  // paged caches: [B, table_stride] page numbers, else nullptr
@@ -48,6 +49,7 @@ struct PrefillKernelParams {
 };
 
 int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
+int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_rotary_table(void *cos_t, void *sin_t, int max_seq_len, int rot_dim, int dtype, hipStream_t stream);
 int launch_fill16(void *arr, uint16_t bits, size_t n, hipStream_t stream);

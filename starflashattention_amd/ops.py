@@ -64,17 +64,21 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
                  batch_size, memory_max_len, num_heads, head_dim, rotary_embedding_dim,
                  max_input_length, num_layer, idx_layer, *, num_splits=0,
                  rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None, kv_layout="blmhd",
-                 block_table=None):
+                 block_table=None, num_heads_kv=None):
     """One decode step (see include/star_flash_attn.h, sfa_decode).  Returns `o` (same tensor).
     kv_layout: "blmhd" = the reference's [B, L, M, H, D] caches; "blhmd" = head-major [B, L, H, M, D];
     "paged" = page pools [num_pages, L, page_size, H, D] addressed through block_table (int32
-    [B, pages_per_seq]); memory_max_len is then the capacity of one sequence."""
+    [B, pages_per_seq]); memory_max_len is then the capacity of one sequence.
+    num_heads_kv (grouped queries, an extension): qkv is then [B, num_heads + 2*num_heads_kv, D] (q heads,
+    k heads, v heads), k_bias / v_bias and the caches carry num_heads_kv heads."""
     lib = _lib.load()
     _require(isinstance(qkv, torch.Tensor) and qkv.dtype in _DTYPES,
              f"qkv must be a float16 or bfloat16 tensor (got {getattr(qkv, 'dtype', type(qkv))})")
     dt, dev = qkv.dtype, qkv.device
     B, H, D, M, L = int(batch_size), int(num_heads), int(head_dim), int(memory_max_len), int(num_layer)
-    _check_gpu_tensor(qkv, "qkv", dt, (B, 3, H, D))
+    Hkv = H if num_heads_kv is None else int(num_heads_kv)
+    _require(Hkv > 0 and H % Hkv == 0, f"num_heads={H} must be a multiple of num_heads_kv={Hkv}")
+    _check_gpu_tensor(qkv, "qkv", dt, (B, 3, H, D) if Hkv == H else (B, H + 2 * Hkv, D))
     _check_gpu_tensor(o, "o", dt, (B, H, D), dev)
     _check_gpu_tensor(seq_len, "seq_len", torch.int32, (B,), dev)
     _require(kv_layout in _lib.KV_LAYOUTS, f"kv_layout must be one of {sorted(_lib.KV_LAYOUTS)} (got {kv_layout!r})")
@@ -84,11 +88,11 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         _require(isinstance(k_cache_table, torch.Tensor) and k_cache_table.dim() == 5,
                  "k_cache_table must be a [num_pages, num_layer, page_size, num_heads, head_dim] pool")
         num_pages, page_size = int(k_cache_table.shape[0]), int(k_cache_table.shape[2])
-        cache_shape = (num_pages, L, page_size, H, D)
+        cache_shape = (num_pages, L, page_size, Hkv, D)
         _check_gpu_tensor(block_table, "block_table", torch.int32, (B, int(block_table.shape[1])), dev)
     else:
         _require(block_table is None, "block_table is only meaningful with kv_layout='paged'")
-        cache_shape = (B, L, M, H, D) if kv_layout == "blmhd" else (B, L, H, M, D)
+        cache_shape = (B, L, M, Hkv, D) if kv_layout == "blmhd" else (B, L, Hkv, M, D)
     _check_gpu_tensor(k_cache_table, "k_cache_table", dt, cache_shape, dev)
     _check_gpu_tensor(v_cache_table, "v_cache_table", dt, cache_shape, dev)
     biases = []
@@ -96,7 +100,7 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         if t is None or t.numel() == 0:
             biases.append(None)
         else:
-            _check_gpu_tensor(t, name, dt, (H, D), dev)
+            _check_gpu_tensor(t, name, dt, (H if name == "q_bias" else Hkv, D), dev)
             biases.append(t)
     for name, t in (("rotary_cos_table", rotary_cos_table), ("rotary_sin_table", rotary_sin_table)):
         if t is not None:
@@ -117,7 +121,8 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         a.head_dim_inv = float(softmax_scale) if softmax_scale else 1.0 / math.sqrt(D)
         a.rotary_embedding_dim = int(rotary_embedding_dim)
         a.max_input_length = int(max_input_length)
-        a.stride = 3 * H * D
+        a.stride = (H + 2 * Hkv) * D
+        a.num_heads_kv = Hkv
         a.num_layer, a.idx_layer = L, int(idx_layer)
         a.num_splits = S
         a.dtype = _DTYPES[dt]

@@ -351,3 +351,55 @@ def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
     with pytest.raises(RuntimeError, match="page_size"):
         sfa.flash_decode(qkv, z, z, z, kp[:, :, :8].contiguous(), vp[:, :, :8].contiguous(), sl, o_p, B, M, H, D, D,
                          M, L, layer, kv_layout="paged", block_table=table)
+
+
+@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64)])
+@pytest.mark.parametrize("group", [2, 4, 8])
+@pytest.mark.parametrize("num_splits", [0, 1, 3])
+def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
+    """Grouped-query decode (num_heads_kv): one workgroup serves the G query heads of a
+    kv head from one pass over the cache.  Checked against the (oracle-validated) multi-head kernel on
+    the expanded problem -- kv heads repeated G times -- and against the fp64 oracle on it."""
+    rng = np.random.default_rng(11)
+    B, Hkv, L, M, layer = 3, 2, 2, 160, 0
+    H = Hkv * group
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    dev = torch.device("cuda:0")
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(tdt).to(dev)
+    qkv = mk(B, H + 2 * Hkv, D)
+    kc, vc = mk(B, L, M, Hkv, D), mk(B, L, M, Hkv, D)
+    qb, kb_, vb_ = mk(H, D), mk(Hkv, D), mk(Hkv, D)
+    lens = [0, 53, M - 1]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    rot = D // 2
+    # the expanded multi-head problem
+    rep = lambda t, dim: t.repeat_interleave(group, dim)
+    qkv_x = torch.stack([qkv[:, :H], rep(qkv[:, H:H + Hkv], 1), rep(qkv[:, H + Hkv:], 1)], 1).contiguous()
+    kc_x, vc_x = rep(kc, 3).contiguous(), rep(vc, 3).contiguous()
+    o = torch.empty((B, H, D), dtype=tdt, device=dev)
+    o_x = torch.empty_like(o)
+    kc_g, vc_g = kc.clone(), vc.clone()
+    sfa.flash_decode(qkv, qb, kb_, vb_, kc_g, vc_g, sl, o, B, M, H, D, rot, M, L, layer, num_splits=num_splits,
+                     num_heads_kv=Hkv)
+    sfa.flash_decode(qkv_x, qb, rep(kb_, 0).contiguous(), rep(vb_, 0).contiguous(), kc_x, vc_x, sl, o_x, B, M, H, D,
+                     rot, M, L, layer, num_splits=num_splits)
+    sfa.check_decode_status()
+    tol = TOL[dtype]
+    np.testing.assert_allclose(o.float().cpu().numpy(), o_x.float().cpu().numpy(), atol=tol / 2, rtol=tol / 2)
+    if group == 2:          # same row grouping as the multi-head kernel: bit-identical
+        assert torch.equal(o, o_x)
+    # appended rows: identical to the expanded run's, everything else untouched
+    assert torch.equal(rep(kc_g, 3), kc_x) and torch.equal(rep(vc_g, 3), vc_x)
+    mask = torch.ones((B, L, M), dtype=torch.bool, device=dev)
+    for b in range(B):
+        mask[b, layer, lens[b]] = False
+        assert not torch.equal(kc_g[b, layer, lens[b]], kc[b, layer, lens[b]])
+    assert torch.equal(kc_g[mask], kc[mask]) and torch.equal(vc_g[mask], vc[mask])
+    # head-major caches work for grouped queries too
+    kc_h, vc_h = (t.permute(0, 1, 3, 2, 4).contiguous() for t in (kc, vc))
+    o_h = torch.empty_like(o)
+    sfa.flash_decode(qkv, qb, kb_, vb_, kc_h, vc_h, sl, o_h, B, M, H, D, rot, M, L, layer, num_splits=num_splits,
+                     num_heads_kv=Hkv, kv_layout="blhmd")
+    assert torch.equal(o_h, o)
+    with pytest.raises(RuntimeError, match="num_heads"):
+        sfa.flash_decode(qkv, qb, kb_, vb_, kc_g, vc_g, sl, o, B, M, H, D, rot, M, L, layer, num_heads_kv=H + 1)

@@ -10,6 +10,8 @@ import starflashattention_amd as sfa
 variants = [int(a) for a in sys.argv[1:]] or [0, 1]
 layouts = os.environ.get("LAYOUTS", "blmhd").split(",")
 B, H, Sk, D = 256, 32, 8192, 128
+GQA = int(os.environ.get("GQA", "1"))       # query heads per kv head (extension): Hq = 32, Hkv = 32 / GQA
+HQ, H = H, H // GQA                         # from here on H = kv heads
 dev = torch.device("cuda:0")
 kc = torch.empty((B, 1, Sk, H, D), dtype=torch.bfloat16, device=dev)
 vc = torch.empty_like(kc)
@@ -17,14 +19,16 @@ for t in (kc, vc):
     flat = t.view(-1)
     for i in range(0, flat.numel(), 1 << 28):
         flat[i:i + (1 << 28)].normal_()
-qkv = torch.randn((B, 3, H, D), device=dev).bfloat16()
+qkv = torch.randn((B, 3, H, D) if GQA == 1 else (B, HQ + 2 * H, D), device=dev).bfloat16()
 sl = torch.full((B,), Sk - 1, dtype=torch.int32, device=dev)
 z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
-nbytes = 2.0 * B * Sk * H * D * 2 + 4 * B * H * D * 2
+nbytes = 2.0 * B * Sk * H * D * 2 + 2 * B * (HQ + H) * D * 2
 for rep in range(2):
     for layout in layouts:
         # the same bytes re-interpreted in the other layout: random data either way
         kw = {"kv_layout": layout.split(":")[0]}
+        if GQA > 1:
+            kw["num_heads_kv"] = H
         if layout.startswith("paged"):          # paged:PS -- pool of B*Sk/PS pages, randomly assigned
             ps = int(layout.split(":")[1])
             shape = (B * Sk // ps, 1, ps, H, D)
@@ -34,8 +38,8 @@ for rep in range(2):
         k, v = kc.view(shape), vc.view(shape)
         for nt in variants:
             os.environ["SFA_DECODE_NT"] = str(nt)
-            o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
-            run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, H, D, D, Sk, 1, 0, **kw)
+            o = torch.empty((B, HQ, D), dtype=torch.bfloat16, device=dev)
+            run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, HQ, D, D, Sk, 1, 0, **kw)
             for _ in range(2):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,4 +50,4 @@ for rep in range(2):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 6
-            print(f"layout {layout} nt {nt}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s", flush=True)
+            print(f"GQA {GQA} layout {layout} nt {nt}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s", flush=True)
