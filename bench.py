@@ -133,13 +133,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
+    # one rank per GPU.  SFA_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks
+    # (ranks then share devices): it exercises this launch/timing path, not RCCL.
+    backend = os.environ.get("SFA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL; barriers + one scalar reduction only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; barriers + one scalar reduction only
+        else:
+            dist.init_process_group(backend)
 
     B, H, S, D = (WORKLOAD[k] for k in ("batch", "heads", "seqlen", "head_dim"))
     causal = WORKLOAD["causal"]
