@@ -17,6 +17,8 @@ fp16 = "--fp16" in sys.argv
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).to(torch.float16 if fp16 else torch.bfloat16) for _ in range(3))
+if "--kvshared" in sys.argv:       # every (batch, head) reads the SAME K/V (stride 0): all re-reads hit L2
+    k, v = k[:1, :1].expand(B, H, S, D), v[:1, :1].expand(B, H, S, D)
 outs = {}
 flops = 4.0 * B * H * S * S * D / (2 if causal else 1)
 def run(impl, n):
