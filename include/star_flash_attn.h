@@ -108,7 +108,7 @@ typedef struct sfa_decode_args {
     int batch_size;
     int memory_max_len;
     int num_heads;
-    int head_dim;                   /* 64 or 128                                      */
+    int head_dim;                   /* 64, 128 or 256                                 */
     float head_dim_inv;             /* softmax scale; <= 0 => 1/sqrt(head_dim)        */
     int rotary_embedding_dim;       /* even, 0..head_dim                              */
     int max_input_length;           /* carried for interface parity; unused           */
@@ -170,7 +170,7 @@ typedef struct sfa_prefill_args {
     int heads_kv;
     int seqlen_q;
     int seqlen_k;
-    int head_dim;                   /* 64 or 128                                      */
+    int head_dim;                   /* 64, 128 or 256                                 */
     int64_t q_stride[3];            /* {batch, head, seq} strides in elements         */
     int64_t k_stride[3];
     int64_t v_stride[3];

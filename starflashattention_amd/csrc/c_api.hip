@@ -127,8 +127,8 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
                     a->batch_size, a->num_heads, a->memory_max_len, a->num_layer);
     if (a->idx_layer < 0 || a->idx_layer >= a->num_layer)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: idx_layer=%d outside [0, num_layer=%d)", a->idx_layer, a->num_layer);
-    if (a->head_dim != 64 && a->head_dim != 128)
-        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128}", a->head_dim);
+    if (a->head_dim != 64 && a->head_dim != 128 && a->head_dim != 256)
+        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128, 256}", a->head_dim);
     if (a->rotary_embedding_dim < 0 || a->rotary_embedding_dim > a->head_dim || (a->rotary_embedding_dim & 1))
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: rotary_embedding_dim=%d must be even and in [0, head_dim]",
                     a->rotary_embedding_dim);

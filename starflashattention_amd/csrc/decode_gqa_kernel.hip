@@ -269,14 +269,16 @@ int launch_t(const DecodeKernelParams &p, hipStream_t stream) {
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_t<Fp16, 128>(p, stream);
+        if (head_dim == 256) return launch_t<Fp16, 256>(p, stream);
         if (head_dim == 64) return launch_t<Fp16, 64>(p, stream);
     } else if (dtype == SFA_DTYPE_BF16) {
         if (head_dim == 128) return launch_t<Bf16, 128>(p, stream);
+        if (head_dim == 256) return launch_t<Bf16, 256>(p, stream);
         if (head_dim == 64) return launch_t<Bf16, 64>(p, stream);
     } else {
         return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", dtype);
     }
-    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128}", head_dim);
+    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128, 256}", head_dim);
 }
 
 }  // namespace sfa

@@ -313,7 +313,8 @@ int launch_decode_t(const DecodeKernelParams &p, int dtype, hipStream_t stream) 
         bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
         if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
         if (p.block_table) {
-            constexpr int UP = 16 / (64 / (D / 8));     // a step = 16 rows: at most two pages (page_size >= 16)
+            // a step of at most 16 rows touches at most two pages (page_size >= 16)
+            constexpr int UP = (16 / (64 / (D / 8))) < 4 ? (16 / (64 / (D / 8))) : 4;
             if (nt) hipLaunchKernelGGL((decode_kernel<Tr, D, UP, true, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((decode_kernel<Tr, D, UP, false, true>), grid, block, 0, stream, p);
         } else {
@@ -337,14 +338,16 @@ int launch_decode_t(const DecodeKernelParams &p, int dtype, hipStream_t stream) 
 int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_decode_t<Fp16, 128>(p, dtype, stream);
+        if (head_dim == 256) return launch_decode_t<Fp16, 256>(p, dtype, stream);
         if (head_dim == 64) return launch_decode_t<Fp16, 64>(p, dtype, stream);
     } else if (dtype == SFA_DTYPE_BF16) {
         if (head_dim == 128) return launch_decode_t<Bf16, 128>(p, dtype, stream);
+        if (head_dim == 256) return launch_decode_t<Bf16, 256>(p, dtype, stream);
         if (head_dim == 64) return launch_decode_t<Bf16, 64>(p, dtype, stream);
     } else {
         return fail(SFA_ERR_BAD_DTYPE, "sfa_decode: dtype %d is not fp16(0)/bf16(1)", dtype);
     }
-    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128}", head_dim);
+    return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_decode: head_dim %d not in {64, 128, 256}", head_dim);
 }
 
 }  // namespace sfa

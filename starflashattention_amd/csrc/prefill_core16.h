@@ -51,16 +51,8 @@ template <> struct Mfma16<Fp16> {
 };
 
 // max / sum over the four lanes {c, c+16, c+32, c+48} that share a query
-__device__ __forceinline__ float quad_max(float x) {
-    x = half_max(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(x), bitcast<uint32_t>(x), false, false);
-    return fmaxf(bitcast<float>(r[0]), bitcast<float>(r[1]));
-}
-__device__ __forceinline__ float quad_sum(float x) {
-    x = half_sum(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(x), bitcast<uint32_t>(x), false, false);
-    return bitcast<float>(r[0]) + bitcast<float>(r[1]);
-}
+__device__ __forceinline__ float quad_max(float x) { return row_pair_max(half_max(x)); }
+__device__ __forceinline__ float quad_sum(float x) { return row_pair_sum(half_sum(x)); }
 
 // Per-wave online-softmax state: two 16-query blocks.
 //   EXACT = false: Q carries scale*log2(e) (rounded to 16 bit), scores are exp2 arguments, msc in log2 units

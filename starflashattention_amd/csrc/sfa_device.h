@@ -76,12 +76,26 @@ __device__ __forceinline__ float dpp_mov(float x) {
 }
 // Sum over aligned groups of LANES (4, 8 or 16) lanes; every lane gets the total.
 // quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140.
+// v_permlane16_swap of a value with itself: a = {row0, row0, row2, row2}, b = {row1, row1, row3, row3}
+// (rows of 16 lanes).  The result elements are copied to scalars before the bit cast:
+// __builtin_bit_cast(float, r[1]) on the vector element itself reads element 0 (clang 19 / ROCm 7.2).
+struct RowPair { float a, b; };
+__device__ __forceinline__ RowPair row_pair(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];
+    return RowPair{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+__device__ __forceinline__ float row_pair_sum(float x) { const RowPair r = row_pair(x); return r.a + r.b; }
+__device__ __forceinline__ float row_pair_max(float x) { const RowPair r = row_pair(x); return fmaxf(r.a, r.b); }
+
 template <int LANES>
 __device__ __forceinline__ float group_sum(float x) {
     x += dpp_mov<0xB1>(x);
     x += dpp_mov<0x4E>(x);
     if (LANES >= 8) x += dpp_mov<0x141>(x);
     if (LANES >= 16) x += dpp_mov<0x140>(x);
+    if (LANES >= 32) x = row_pair_sum(x);   // across the two 16-lane rows of a 32-lane half
     return x;
 }
 // Value held by the same lane of the other 32-lane half (lane ^ 32).

@@ -134,7 +134,7 @@ def test_decode_partial_rotary_golden(sfa, decode_golden):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("D,H", [(128, 5), (64, 3)])
+@pytest.mark.parametrize("D,H", [(128, 5), (64, 3), (256, 2)])
 def test_decode_random_shapes(sfa, dtype, D, H):
     rng = np.random.default_rng(11 + D + H)
     B, L, M = 3, 2, 700
@@ -295,7 +295,7 @@ def test_decode_head_major_kv_layout(sfa, dtype, num_splits):
         sfa.flash_decode(qkv, z, z, z, kc_a, vc_a, sl, o_h, B, M, H, D, D, M, L, layer, kv_layout="blhmd")
 
 
-@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64)])
+@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64), ("fp16", 256)])
 @pytest.mark.parametrize("num_splits", [0, 1, 3])
 @pytest.mark.parametrize("page_size", [16, 64])
 def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
@@ -332,7 +332,11 @@ def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
     sfa.flash_decode(qkv, z, z, z, kp, vp, sl, o_p, B, M, H, D, D, M, L, layer, num_splits=num_splits,
                      kv_layout="paged", block_table=table)
     sfa.check_decode_status()
-    assert torch.equal(o_a, o_p)
+    if D >= 128:            # same rows per step as the contiguous kernel: bit-identical
+        assert torch.equal(o_a, o_p)
+    else:                   # D=64 pages in 16-row steps, the contiguous kernel in 32-row steps
+        np.testing.assert_allclose(o_p.float().cpu().numpy(), o_a.float().cpu().numpy(), atol=TOL[dtype] / 4,
+                                   rtol=TOL[dtype] / 4)
     changed_k = (kp != kp0).flatten(2).any(-1)             # [num_pages, L]
     for b in range(B):
         pg, row = int(perm[b, lens[b] // page_size]), lens[b] % page_size
@@ -353,7 +357,7 @@ def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
                          M, L, layer, kv_layout="paged", block_table=table)
 
 
-@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64)])
+@pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64), ("bf16", 256)])
 @pytest.mark.parametrize("group", [2, 4, 8])
 @pytest.mark.parametrize("num_splits", [0, 1, 3])
 def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
