@@ -117,8 +117,10 @@ def bench_decode(torch, sfa, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults long enough to time the steady state: the first ~20 launches after start-up run up to
+    # 6 % slower (10 steps after 3 warm-ups: 997 TFLOPS; 100 after 20: 1058 on the same device)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
@@ -213,7 +215,7 @@ def main():
             try:
                 del q, k, v, out
                 torch.cuda.empty_cache()
-                rec["decode_roofline"] = bench_decode(torch, sfa, max(3, args.steps // 2), 2)
+                rec["decode_roofline"] = bench_decode(torch, sfa, min(50, max(3, args.steps // 2)), 3)
             except Exception as e:                      # the headline number must still print
                 rec["decode_roofline"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:

@@ -22,8 +22,8 @@ for s in $STEPS; do
     smoke) run_step smoke 300 python __graft_entry__.py smoke ;;
     tests) run_step tests 900 python -u -m pytest tests -m gpu -x -q --timeout 120 ;;
     testsall) run_step tests 900 python -u -m pytest tests -m gpu -q --timeout 120 ;;
-    bench) run_step bench 600 python bench.py --steps 10 --warmup 3 ;;
-    benchfast) run_step bench 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode ;;
+    bench) run_step bench 600 python bench.py ;;
+    benchfast) run_step bench 300 python bench.py --no-cpu-baseline --no-decode ;;
     prefill) run_step prefill 300 python -u -m pytest tests/test_prefill_gpu.py -m gpu -x -q --timeout 120 ;;
     decode) run_step decode 300 python -u -m pytest tests/test_decode_gpu.py -m gpu -x -q --timeout 120 ;;
     ab) run_step ab 300 python -u tools/prefill_ab.py ${AB_ARGS:-0 1} ;;

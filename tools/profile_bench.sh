@@ -5,7 +5,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline"
+ARGS="--steps 100 --warmup 20 --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 < /dev/null
 echo "trace rc=$?"; tail -1 $OUT/trace.log | cut -c1-400
