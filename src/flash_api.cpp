@@ -128,7 +128,7 @@ at::Tensor mha_fwd_cuda(at::Tensor &qkv, at::Tensor &q_bias, at::Tensor &k_bias,
     set_default_params(params);
     hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
 
-    sfa_decode_args a;
+    sfa_decode_args a = {};             // zero: the reference layout, no paging, num_heads_kv = num_heads
     a.qkv = input.qkv;
     a.q_bias = input.q_bias;
     a.k_bias = input.k_bias;
@@ -197,7 +197,7 @@ std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const 
     if (return_lse) lse = at::empty({q.size(0), q.size(1), q.size(2)}, q.options().dtype(at::kFloat));
 
     c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
-    sfa_prefill_args a;
+    sfa_prefill_args a = {};
     a.q = q.data_ptr(); a.k = k.data_ptr(); a.v = v.data_ptr(); a.o = out.data_ptr();
     a.lse = return_lse ? lse.data_ptr<float>() : nullptr;
     a.batch = (int)q.size(0); a.heads_q = (int)q.size(1); a.heads_kv = (int)k.size(1);

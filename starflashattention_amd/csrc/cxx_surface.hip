@@ -53,7 +53,7 @@ template <typename T> constexpr int dtype_of() {
 
 template <typename T>
 void run_flash_decoder(Flash_decoder_input &in, Flash_decoder_params &params, hipStream_t stream) {
-    sfa_decode_args a;
+    sfa_decode_args a = {};             // zero: the reference layout, no paging, num_heads_kv = num_heads
     a.qkv = in.qkv;
     a.q_bias = in.q_bias;
     a.k_bias = in.k_bias;
