@@ -66,6 +66,25 @@ def test_argument_validation_without_gpu(lib):
     assert b"workspace" in lib.sfa_last_error()
     a.workspace, a.workspace_bytes = 0x2000, 16
     assert lib.sfa_decode(ctypes.byref(a), None) == -5          # workspace too small
+    # ABI v2 extensions: cache layouts, paging, grouped queries
+    a.kv_layout = 3
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"kv_layout" in lib.sfa_last_error()
+    a.kv_layout = _lib.KV_LAYOUTS["paged"]
+    assert lib.sfa_decode(ctypes.byref(a), None) == -1 and b"block_table" in lib.sfa_last_error()
+    a.block_table, a.page_size, a.num_pages, a.block_table_stride = 0x3000, 8, 4, 2
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"page_size" in lib.sfa_last_error()
+    a.page_size, a.block_table_stride = 16, 0
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"cover memory_max_len" in lib.sfa_last_error()
+    a.block_table_stride = 1
+    assert lib.sfa_decode(ctypes.byref(a), None) == -5          # past the paging checks: workspace again
+    a.kv_layout = _lib.KV_LAYOUTS["blhmd"]
+    a.num_heads, a.num_heads_kv = 6, 4
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"num_heads_kv" in lib.sfa_last_error()
+    a.num_heads, a.num_heads_kv = 12, 4                         # group of 3: not in {1, 2, 4, 8}
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2
+    a.num_heads, a.num_heads_kv, a.kv_layout = 8, 4, _lib.KV_LAYOUTS["paged"]
+    assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"paged" in lib.sfa_last_error()
+    assert lib.sfa_status_string(-8) == b"block_table entry out of range"
     p = _lib.PrefillArgs()
     assert lib.sfa_prefill_fwd(ctypes.byref(p), None) == -1
     assert lib.sfa_status_string(-7) == b"seq_len out of range"
