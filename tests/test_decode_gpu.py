@@ -407,3 +407,54 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     assert torch.equal(o_h, o)
     with pytest.raises(RuntimeError, match="num_heads"):
         sfa.flash_decode(qkv, qb, kb_, vb_, kc_g, vc_g, sl, o, B, M, H, D, rot, M, L, layer, num_heads_kv=H + 1)
+
+
+def test_decode_layouts_agree_at_scale(sfa):
+    """BASELINE config 4's sequence length and head count at a batch the box can hold thrice: the
+    reference layout, the head-major layout and a randomly paged pool (non-temporal loads kick in:
+    the caches exceed the Infinity Cache) give bit-identical outputs and appended rows; one (b, h) slice
+    against the fp64 oracle."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    B, H, D, L, M, ps = 12, 32, 128, 1, 8192, 64
+    tdt = torch.bfloat16
+    kc = torch.empty((B, L, M, H, D), dtype=tdt, device=dev).normal_()
+    vc = torch.empty((B, L, M, H, D), dtype=tdt, device=dev).normal_()
+    qkv = torch.randn((B, 3, H, D), device=dev).to(tdt)
+    lens = torch.randint(4000, M - 1, (B,), dtype=torch.int32)
+    lens[0], lens[1] = M - 1, 0
+    sl = lens.to(dev)
+    z = torch.zeros(0, dtype=tdt, device=dev)
+    outs = {}
+    # reference layout
+    k_a, v_a = kc.clone(), vc.clone()
+    outs["blmhd"] = torch.empty((B, H, D), dtype=tdt, device=dev)
+    sfa.flash_decode(qkv, z, z, z, k_a, v_a, sl, outs["blmhd"], B, M, H, D, D, M, L, 0)
+    # head-major
+    k_h, v_h = (t.permute(0, 1, 3, 2, 4).contiguous() for t in (kc, vc))
+    outs["blhmd"] = torch.empty_like(outs["blmhd"])
+    sfa.flash_decode(qkv, z, z, z, k_h, v_h, sl, outs["blhmd"], B, M, H, D, D, M, L, 0, kv_layout="blhmd")
+    # paged: the same rows scattered through a shuffled pool
+    pps = M // ps
+    table = torch.randperm(B * pps, device=dev).to(torch.int32).view(B, pps)
+    def to_pool(c):
+        pool = torch.empty((B * pps, L, ps, H, D), dtype=tdt, device=dev)
+        pool[table.long().view(-1)] = c.view(B, L, pps, ps, H, D).permute(0, 2, 1, 3, 4, 5).reshape(B * pps, L, ps, H, D)
+        return pool
+    k_p, v_p = to_pool(kc), to_pool(vc)
+    outs["paged"] = torch.empty_like(outs["blmhd"])
+    sfa.flash_decode(qkv, z, z, z, k_p, v_p, sl, outs["paged"], B, M, H, D, D, M, L, 0, kv_layout="paged",
+                     block_table=table)
+    sfa.check_decode_status()
+    assert torch.equal(outs["blmhd"], outs["blhmd"]) and torch.equal(outs["blmhd"], outs["paged"])
+    assert torch.equal(k_h.permute(0, 1, 3, 2, 4), k_a) and torch.equal(v_h.permute(0, 1, 3, 2, 4), v_a)
+    for b in (0, 1, 5):
+        pos = int(lens[b])
+        pg = int(table[b, pos // ps])
+        assert torch.equal(k_p[pg, 0, pos % ps], k_a[b, 0, pos]) and torch.equal(v_p[pg, 0, pos % ps], v_a[b, 0, pos])
+    # one (b, h) slice against the oracle
+    b, h = 5, 7
+    f = lambda t: t.float().cpu().numpy()
+    ref = decode_ref(f(qkv[b:b + 1, :, h:h + 1]), f(kc[b:b + 1, :, :, h:h + 1]), f(vc[b:b + 1, :, :, h:h + 1]),
+                     [int(lens[b])], 0, D, dtype="bf16")
+    np.testing.assert_allclose(f(outs["blmhd"][b:b + 1, h:h + 1]), ref["o"], atol=TOL["bf16"], rtol=TOL["bf16"])
