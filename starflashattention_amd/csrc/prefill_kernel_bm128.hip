@@ -17,6 +17,8 @@
 //   barrier(t) follows.  K runs two tiles ahead so the first K fragments of H(t+1) are read during
 //   the last slots of H(t).  Buffer safety: K(t+3) overwrites K(t), last read in H(t-1); V(t+1)
 //   overwrites V(t-1), last read in H(t-1) -- both before barrier(t-1).
+#include <cstdlib>
+
 #include "prefill_core.h"
 
 namespace sfa {
@@ -302,7 +304,14 @@ template <class Tr, int D>
 int launch_t(const PrefillKernelParams &p_in, bool causal, int force, hipStream_t stream) {
     PrefillKernelParams p = p_in;
     p.nq_tiles = (p.Sq + kBM2 - 1) / kBM2;              // 128-row q-tiles
-    const size_t lds = Lds<D, kBN2, 3, 2>::TOTAL;
+    size_t lds = Lds<D, kBN2, 3, 2>::TOTAL;
+    if (const char *e = std::getenv("SFA_BM128_ONE_WG")) {      // diagnostic: one workgroup (one wave per SIMD) per CU
+        if (std::atoi(e)) {
+            lds = 100 * 1024;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_bm128<Tr, D, true, 2, 6>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+    }
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads2);
     // same policy as the 256-row kernel: prescaled Q for output-only calls, exact scale when the
     // log-sum-exp is returned (SFA_PREFILL_IMPL 21 / 22 force one or the other)
