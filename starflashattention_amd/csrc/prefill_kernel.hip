@@ -39,6 +39,13 @@
 //     more than 2^8 over the reference max (wave-uniform branch, almost never taken after the
 //     first tiles).  exp2 arguments stay <= 8, so P <= 256: bf16/fp16 keep the same RELATIVE
 //     precision and the fp32 accumulators have ample headroom.
+//   * Two numeric flavours (template ORD): 2 = exact scale (scores are the fp32 QK^T, one FMA by
+//     scale*log2(e) in front of v_exp; used when the log-sum-exp is returned) and 6 = prescaled Q
+//     (Q * scale*log2(e) rounded to 16 bit once per q-tile, the first QK^T MFMA of a half-step starts
+//     from C = -reference max, so scores leave the MFMA as exp2 arguments and the scale/subtract pass
+//     is gone: +5 %; output-only calls).  launch_prefill_main picks by p.lse.
+//   * Where the K/V tiles of a stream position live is computed once per step on the scalar unit
+//     (tile_src), not inside every staging load.
 //   * LDS images use PADDED rows (prefill_common.h would XOR-swizzle): every read address is one
 //     lane-constant base plus a compile-time immediate -- two LDS address registers in total --
 //     and SQ_LDS_BANK_CONFLICT measures 0.
