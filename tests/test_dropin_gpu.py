@@ -122,3 +122,48 @@ def test_cpp_harness_known_answers():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all cases ok" in r.stdout and "REJECTED (as it must be)" in r.stdout
     assert r.stdout.count(" ok") >= 6
+
+
+def test_entry_points_are_graph_capturable():
+    """the C-ABI entry points allocate nothing and never synchronise, so a decode
+    step and a prefill call can be captured into a HIP graph (after a warm-up that sizes the workspace)
+    and replayed on new data."""
+    import starflashattention_amd as sfa
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    B, H, D, L, M = 4, 8, 128, 1, 512
+    tdt = torch.float16
+    qkv = torch.randn(B, 3, H, D, device=dev).to(tdt)
+    kc = torch.randn(B, L, M, H, D, device=dev).to(tdt)
+    vc = torch.randn(B, L, M, H, D, device=dev).to(tdt)
+    sl = torch.tensor([5, 100, 300, 400], dtype=torch.int32, device=dev)
+    o = torch.empty(B, H, D, device=dev, dtype=tdt)
+    z = torch.zeros(0, dtype=tdt, device=dev)
+    q = torch.randn(2, 4, 300, D, device=dev).to(tdt)
+    k = torch.randn(2, 4, 300, D, device=dev).to(tdt)
+    v = torch.randn(2, 4, 300, D, device=dev).to(tdt)
+    po = torch.empty_like(q)
+
+    def work():
+        sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, D, M, L, 0, num_splits=3)
+        sfa.flash_attn_fwd(q, k, v, causal=True, out=po)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):          # warm-up on the capture stream: sizes its workspace
+        work()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        work()
+    # new data in the same buffers, then replay
+    kc0, vc0 = kc.clone(), vc.clone()
+    qkv.copy_(torch.randn(B, 3, H, D, device=dev).to(tdt))
+    q.copy_(torch.randn(2, 4, 300, D, device=dev).to(tdt))
+    kc.copy_(kc0); vc.copy_(vc0)
+    g.replay()
+    torch.cuda.synchronize()
+    o_g, po_g, kc_g = o.clone(), po.clone(), kc.clone()
+    kc.copy_(kc0); vc.copy_(vc0)
+    work()
+    torch.cuda.synchronize()
+    assert torch.equal(o, o_g) and torch.equal(po, po_g) and torch.equal(kc, kc_g)
