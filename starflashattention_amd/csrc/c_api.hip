@@ -144,8 +144,6 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     const long long stride = a->stride > 0 ? a->stride : row;
     if (stride < row || (stride % 8) != 0)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: qkv stride %lld must be >= (H + 2*Hkv)*D and a multiple of 8", stride);
-    if (group != 1 && a->kv_layout == SFA_KV_PAGED)
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: paged caches with num_heads_kv != num_heads are not supported");
     if (a->num_splits > 1024)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_splits=%d > 1024", a->num_splits);
     if (a->kv_layout != SFA_KV_BLMHD && a->kv_layout != SFA_KV_BLHMD && a->kv_layout != SFA_KV_PAGED)

@@ -22,13 +22,14 @@ namespace {
 
 using namespace decode;
 
-template <class Tr, int D, int G, bool NT>
+template <class Tr, int D, int G, bool NT, bool PAGED = false>
 __global__ void __launch_bounds__(kDecodeWaves * 64)
 decode_gqa_kernel(const DecodeKernelParams p) {
     constexpr int W = kDecodeWaves;
     constexpr int LPR = D / 8;          // lanes per cache row
     constexpr int GR = 64 / LPR;        // cache rows per wave-instruction
-    constexpr int U = G >= 4 ? 2 : 4;   // row groups per step (registers: G streams of 10 floats each)
+    constexpr int U0 = G >= 4 ? 2 : 4;  // row groups per step (registers: G streams of 10 floats each)
+    constexpr int U = (PAGED && GR * U0 > 16) ? 16 / GR : U0;   // paged: a step (<= 16 rows) spans <= 2 pages
     constexpr int STEP = GR * U;
     const int hk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -113,28 +114,52 @@ decode_gqa_kernel(const DecodeKernelParams p) {
     const int r1 = min(pos, r0 + rows_per_split);
     int per_wave = (r1 - r0 + W - 1) / W;
     per_wave = (per_wave + STEP - 1) / STEP * STEP;
-    const int w0 = min(r1, r0 + wave * per_wave);
-    const int w1 = min(r1, w0 + per_wave);
+    const int w0 = __builtin_amdgcn_readfirstlane(min(r1, r0 + wave * per_wave));   // wave-uniform
+    const int w1 = __builtin_amdgcn_readfirstlane(min(r1, w0 + per_wave));
 
     const long long rs = p.kv_row_stride;
-    const long long head_base = ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride + sub * 8;
+    // paged: see decode_kernel.hip (two scalar table look-ups per step, selected per lane)
+    const long long head_base = PAGED ? (long long)p.layer * (rs << p.page_shift) + (long long)hk * p.kv_head_stride + sub * 8
+                                      : ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride + sub * 8;
     const uint16_t *kb = p.k_cache + head_base;
     const uint16_t *vb = p.v_cache + head_base;
+    const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;
+    const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    auto page_of = [&](int idx) -> int {
+        int pg = tbl[idx];
+        if ((unsigned)pg >= (unsigned)p.num_pages) {
+            if (tid == 0) atomicOr(p.status, 2);
+            pg = 0;
+        }
+        return pg;
+    };
+    auto row_off = [&](int row, int i0, long long o0, long long o1) -> long long {
+        if (!PAGED) return (long long)row * rs;
+        return ((row >> p.page_shift) == i0 ? o0 : o1) + (long long)(row & pmask) * rs;
+    };
 
     Stream st[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) st[g].init();
 
     auto load = [&](uint4 (&kk)[U], uint4 (&vv)[U], int t) {
+        int i0 = 0;
+        long long o0 = 0, o1 = 0;
+        if (PAGED) {
+            i0 = t >> p.page_shift;
+            const int i1 = min(i0 + 1, (w1 - 1) >> p.page_shift);
+            o0 = page_of(i0) * p.page_stride;
+            o1 = page_of(i1) * p.page_stride;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * GR + grp, w1 - 1);      // clamp: loads stay in range
-            kk[u] = ld16<NT>(kb + (long long)row * rs);
+            kk[u] = ld16<NT>(kb + row_off(row, i0, o0, o1));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = min(t + u * GR + grp, w1 - 1);
-            vv[u] = ld16<NT>(vb + (long long)row * rs);
+            vv[u] = ld16<NT>(vb + row_off(row, i0, o0, o1));
         }
     };
     auto consume = [&](const uint4 (&kk)[U], const uint4 (&vv)[U], int t) {
@@ -191,7 +216,8 @@ decode_gqa_kernel(const DecodeKernelParams p) {
             unpack8<Tr>(vpk, x);
 #pragma unroll
             for (int g = 0; g < G; ++g) st[g].merge(dn[g] * p.scale_log2, 1.0f, x);
-            const long long roff = (long long)pos * rs;         // append: LPR lanes x 16 B = one row each
+            long long roff = (long long)pos * rs;               // append: LPR lanes x 16 B = one row each
+            if (PAGED) roff = page_of(pos >> p.page_shift) * p.page_stride + (long long)(pos & pmask) * rs;
             *reinterpret_cast<uint4 *>(p.k_cache + head_base + roff) = kpk;
             *reinterpret_cast<uint4 *>(p.v_cache + head_base + roff) = vpk;
         }
@@ -248,8 +274,13 @@ int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
     bool nt = 4ll * p.B * p.L * p.M * p.Hkv * D > (256ll << 20);       // see decode_kernel.hip
     if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
-    if (nt) hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, false>), grid, block, 0, stream, p);
+    if (p.block_table) {
+        if (nt) hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, false, true>), grid, block, 0, stream, p);
+    } else {
+        if (nt) hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, false>), grid, block, 0, stream, p);
+    }
     return check_launch("decode_gqa_kernel");
 }
 

@@ -302,7 +302,6 @@ int launch_decode_t(const DecodeKernelParams &p, int dtype, hipStream_t stream) 
     int rc;
     if (p.Hkv != p.H) {
         // grouped queries: one workgroup per (batch, kv head, split) serves the whole group
-        if (p.block_table) return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: paged caches with num_heads_kv != num_heads are not supported");
         rc = launch_decode_gqa(p, dtype, D, stream);
     } else {
         dim3 grid(p.H, p.num_splits, p.B), block(kDecodeWaves * 64);

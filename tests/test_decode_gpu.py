@@ -405,6 +405,26 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     sfa.flash_decode(qkv, qb, kb_, vb_, kc_h, vc_h, sl, o_h, B, M, H, D, rot, M, L, layer, num_splits=num_splits,
                      num_heads_kv=Hkv, kv_layout="blhmd")
     assert torch.equal(o_h, o)
+    # ... and so do paged pools
+    ps = 16
+    pps = M // ps
+    table = torch.from_numpy(rng.permutation(B * pps + 3)[:B * pps].astype(np.int32)).view(B, pps).to(dev)
+    def to_pool(c):
+        pool = torch.zeros((B * pps + 3, L, ps, Hkv, D), dtype=tdt, device=dev)
+        pool[table.long().view(-1)] = c.view(B, L, pps, ps, Hkv, D).permute(0, 2, 1, 3, 4, 5).reshape(B * pps, L, ps, Hkv, D)
+        return pool
+    kp, vp = to_pool(kc), to_pool(vc)
+    o_p = torch.empty_like(o)
+    sfa.flash_decode(qkv, qb, kb_, vb_, kp, vp, sl, o_p, B, M, H, D, rot, M, L, layer, num_splits=num_splits,
+                     num_heads_kv=Hkv, kv_layout="paged", block_table=table)
+    sfa.check_decode_status()
+    if D >= 128:
+        assert torch.equal(o_p, o)
+    else:
+        np.testing.assert_allclose(o_p.float().cpu().numpy(), o.float().cpu().numpy(), atol=tol / 4, rtol=tol / 4)
+    for b in range(B):
+        pg, row = int(table[b, lens[b] // ps]), lens[b] % ps
+        assert torch.equal(kp[pg, layer, row], kc_g[b, layer, lens[b]])
     with pytest.raises(RuntimeError, match="num_heads"):
         sfa.flash_decode(qkv, qb, kb_, vb_, kc_g, vc_g, sl, o, B, M, H, D, rot, M, L, layer, num_heads_kv=H + 1)
 
