@@ -211,6 +211,24 @@ def main():
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},
         }
+        if world == 1:
+            # supplementary, NOT the headline: the opt-in prescaled-Q kernels (fast_scale=True)
+            try:
+                fs = lambda: sfa.flash_attn_fwd(q, k, v, causal=causal, out=out, fast_scale=True)
+                for _ in range(10):
+                    fs()
+                torch.cuda.synchronize()
+                e0.record()
+                nfs = max(10, args.steps // 4)
+                for _ in range(nfs):
+                    fs()
+                e1.record()
+                torch.cuda.synchronize()
+                rec["fast_scale_variant"] = {
+                    "tflops": round(flops_step / (e0.elapsed_time(e1) / nfs * 1e-3) / 1e12, 2),
+                    "note": "opt-in fast_scale=True (Q*scale rounded to bf16 once; not the default path)"}
+            except Exception as e:
+                rec["fast_scale_variant"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_decode:
             try:
                 del q, k, v, out

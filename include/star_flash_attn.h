@@ -170,7 +170,7 @@ typedef struct sfa_prefill_args {
     int heads_kv;
     int seqlen_q;
     int seqlen_k;
-    int head_dim;                   /* 64, 128 or 256                                 */
+    int head_dim;                   /* 64 or 128                                      */
     int64_t q_stride[3];            /* {batch, head, seq} strides in elements         */
     int64_t k_stride[3];
     int64_t v_stride[3];
@@ -178,6 +178,13 @@ typedef struct sfa_prefill_args {
     float softmax_scale;            /* <= 0 => 1/sqrt(head_dim)                       */
     int causal;
     int dtype;                      /* sfa_dtype                                      */
+    int fast_scale;                 /* 0 (default): scores are the fp32 Q.K^T times the scale in fp32.
+                                       nonzero, and only when lse == NULL: allow the prescaled-Q kernels
+                                       (Q * scale * log2(e) rounded to the 16-bit dtype once, ~5 % faster):
+                                       every score then carries a relative error of up to 2^-9 (bf16) /
+                                       2^-12 (fp16) of the |q_i k_i| it sums -- invisible for unit-variance
+                                       data, several per cent of a softmax weight once logits reach
+                                       hundreds (ABI v2)                                                */
 } sfa_prefill_args;
 
 int sfa_prefill_fwd(const sfa_prefill_args *args, void *stream);

@@ -180,7 +180,7 @@ void check_errors() {
 // Prefill forward: q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D] (head_dim contiguous, any other strides).
 std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const at::Tensor &v,
                                 c10::optional<at::Tensor> out_, bool causal, double softmax_scale,
-                                bool return_lse) {
+                                bool return_lse, bool fast_scale) {
     TORCH_CHECK(q.defined() && q.is_cuda(), "star_flash_attn: q must live on a HIP device");
     const int dt = dtype_code(q, "q");
     for (const at::Tensor *t : {&q, &k, &v}) {
@@ -208,6 +208,7 @@ std::vector<at::Tensor> mha_fwd(const at::Tensor &q, const at::Tensor &k, const 
     }
     a.softmax_scale = (float)softmax_scale;
     a.causal = causal ? 1 : 0;
+    a.fast_scale = fast_scale ? 1 : 0;      // opt-in: prescaled-Q kernels (include/star_flash_attn.h)
     a.dtype = dt;
     check_status(sfa_prefill_fwd(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.device().index()).stream()), "mha_fwd");
     if (return_lse) return {out, lse};
@@ -238,7 +239,7 @@ PYBIND11_MODULE(star_flash_attn, m) {
           "Synchronise the current stream and raise if a decode call saw an out-of-range seq_len");
     m.def("mha_fwd", &mha_fwd, "Attention forward (prefill): returns [out] or [out, lse]",
           py::arg("q"), py::arg("k"), py::arg("v"), py::arg("out") = py::none(), py::arg("causal") = false,
-          py::arg("softmax_scale") = 0.0, py::arg("return_lse") = false);
+          py::arg("softmax_scale") = 0.0, py::arg("return_lse") = false, py::arg("fast_scale") = false);
     m.def("compute_rotary_table", &compute_rotary_table, "cos/sin LUT [max_seq_len, rot_dim/2]",
           py::arg("max_seq_len"), py::arg("rot_dim"), py::arg("dtype"), py::arg("device"));
 }

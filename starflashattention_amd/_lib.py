@@ -54,6 +54,7 @@ class PrefillArgs(ctypes.Structure):
         ("q_stride", ctypes.c_int64 * 3), ("k_stride", ctypes.c_int64 * 3),
         ("v_stride", ctypes.c_int64 * 3), ("o_stride", ctypes.c_int64 * 3),
         ("softmax_scale", ctypes.c_float), ("causal", ctypes.c_int), ("dtype", ctypes.c_int),
+        ("fast_scale", ctypes.c_int),
     ]
 
 

@@ -262,6 +262,7 @@ int sfa_prefill_fwd(const sfa_prefill_args *a, void *stream) {
     p.v = (const uint16_t *)a->v;
     p.o = (uint16_t *)a->o;
     p.lse = a->lse;
+    p.fast_scale = a->fast_scale != 0 && a->lse == nullptr;
     p.B = a->batch;
     p.Hq = a->heads_q;
     p.Hkv = a->heads_kv;

@@ -4,8 +4,9 @@
 //     problems take the 128-row geometry (prefill_kernel_bm128.hip: four times the workgroups).
 //     Each geometry comes in two numeric flavours: exact scale (scores = fp32 QK^T times the scale in
 //     fp32) and prescaled Q (Q * scale * log2 e rounded to 16 bit once per q-tile, the scale pass
-//     gone from the inner loop: +5 %).  Calls that return the log-sum-exp get the exact flavour,
-//     output-only calls the prescaled one; within a flavour the two geometries are bit-identical.
+//     gone from the inner loop: +5 %, score error growing with the logits).  Exact is the default;
+//     the prescaled flavour runs only for callers that set sfa_prefill_args.fast_scale and want no
+//     log-sum-exp.  Within a flavour the two geometries are bit-identical.
 //   SFA_PREFILL_IMPL=0 / 1 / 20 force the baseline generation / the 256-row / the 128-row kernel
 //   (flavour by the rule above); 3 / 10 and 21 / 22 force prescaled / exact of the 256- and 128-row
 //   kernels; 2 and 4 are diagnostic variants (tools/prefill_ab.py, tools/prefill_stamps.py).

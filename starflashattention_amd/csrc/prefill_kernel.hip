@@ -43,7 +43,7 @@
 //     scale*log2(e) in front of v_exp; used when the log-sum-exp is returned) and 6 = prescaled Q
 //     (Q * scale*log2(e) rounded to 16 bit once per q-tile, the first QK^T MFMA of a half-step starts
 //     from C = -reference max, so scores leave the MFMA as exp2 arguments and the scale/subtract pass
-//     is gone: +5 %; output-only calls).  launch_prefill_main picks by p.lse.
+//     is gone: +5 %; opt-in, sfa_prefill_args.fast_scale).  launch_prefill_main picks.
 //   * Where the K/V tiles of a stream position live is computed once per step on the scalar unit
 //     (tile_src), not inside every staging load.
 //   * LDS images use PADDED rows (prefill_common.h would XOR-swizzle): every read address is one
@@ -466,11 +466,12 @@ int launch_cfg(const PrefillKernelParams &p, int dtype, int head_dim, bool causa
 
 }  // namespace
 
-// Exact-scale kernel (ORD 2) when the caller wants the log-sum-exp back; prescaled-Q kernel (ORD 6) for
-// output-only calls (inference prefill): +5 % (990 vs 940 TFLOPS), O within one 16-bit rounding of the
-// exact kernel's, but the scores carry Q*scale rounded to 16 bit, which an LSE consumer would see.
+// Exact-scale kernel (ORD 2) by default; the prescaled-Q kernel (ORD 6, +5 %) only when the caller opted in
+// (sfa_prefill_args.fast_scale) and wants no log-sum-exp: its scores carry Q*scale rounded to 16 bit --
+// O within one 16-bit rounding of the exact kernel's for unit-variance data, but the score error grows
+// with the logits (tests/test_prefill_gpu.py::test_prefill_extreme_logits).
 int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    if (p.lse == nullptr) return launch_cfg<2, 6, 0>(p, dtype, head_dim, causal, stream);
+    if (p.fast_scale) return launch_cfg<2, 6, 0>(p, dtype, head_dim, causal, stream);
     return launch_cfg<2, 2, 0>(p, dtype, head_dim, causal, stream);     // prefetch distance 2, staged softmax
 }
 // forced / diagnostic variants for the tests, tools/prefill_ab.py and tools/prefill_*stamps.py

@@ -404,11 +404,11 @@ int launch_flavour(const PrefillKernelParams &p, int dtype, int head_dim, bool c
 
 }  // namespace
 
-// force: 0 = by policy (exact scale when the log-sum-exp is returned, prescaled Q otherwise),
+// force: 0 = by policy (exact scale unless the caller opted into the prescaled-Q flavour),
 //        1 = prescaled, 2 = exact
 int launch_prefill_x16(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
                        int force) {
-    const bool exact = force == 0 ? p.lse != nullptr : force == 2;
+    const bool exact = force == 0 ? p.fast_scale == 0 : force == 2;
     if (exact) return launch_flavour<true>(p, dtype, head_dim, causal, stream);
     return launch_flavour<false>(p, dtype, head_dim, causal, stream);
 }

@@ -313,9 +313,9 @@ int launch_t(const PrefillKernelParams &p_in, bool causal, int force, hipStream_
         }
     }
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads2);
-    // same policy as the 256-row kernel: prescaled Q for output-only calls, exact scale when the
-    // log-sum-exp is returned (SFA_PREFILL_IMPL 21 / 22 force one or the other)
-    const bool prescaled = force == 0 ? p.lse == nullptr : force == 1;
+    // same policy as the 256-row kernel: exact scale unless the caller opted into the prescaled-Q
+    // flavour (SFA_PREFILL_IMPL 21 / 22 force one or the other)
+    const bool prescaled = force == 0 ? p.fast_scale != 0 : force == 1;
     if (prescaled) {
         if (causal) hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, true, 2, 6>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((prefill_kernel_bm128<Tr, D, false, 2, 6>), grid, block, lds, stream, p);

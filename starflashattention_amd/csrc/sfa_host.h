@@ -46,6 +46,7 @@ struct PrefillKernelParams {
     int nq_tiles;           // workgroup slots per (batch, head) -- set by each kernel's launcher
     int pairs_per_wg;       // prefill_kernel.hip: balanced q-tile pairs one workgroup walks (1 or 2)
     int bh_per_xcd;         // ceil(B*Hq / 8)
+    int fast_scale;         // caller allows the prescaled-Q flavour (only used when lse == nullptr)
 };
 
 int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);

@@ -154,9 +154,11 @@ def check_decode_status(device=None):
         _lib.check(st)
 
 
-def flash_attn_fwd(q, k, v, causal=False, softmax_scale=None, out=None, return_lse=False):
+def flash_attn_fwd(q, k, v, causal=False, softmax_scale=None, out=None, return_lse=False, fast_scale=False):
     """O = softmax(mask(Q K^T * scale)) V.   q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D] (any batch/head/seq
-    strides, D contiguous), fp16 or bf16, D in {64,128}.  causal is bottom-right aligned."""
+    strides, D contiguous), fp16 or bf16, D in {64,128}.  causal is bottom-right aligned.
+    fast_scale=True (ignored with return_lse) allows the prescaled-Q kernels: ~5 % faster, the scale is
+    folded into Q in 16 bit, so the score error grows with the logits (include/star_flash_attn.h)."""
     lib = _lib.load()
     _require(isinstance(q, torch.Tensor) and q.dtype in _DTYPES,
              f"q must be float16 or bfloat16 (got {getattr(q, 'dtype', type(q))})")
@@ -185,6 +187,7 @@ def flash_attn_fwd(q, k, v, causal=False, softmax_scale=None, out=None, return_l
     a.softmax_scale = float(softmax_scale) if softmax_scale else 0.0
     a.causal = 1 if causal else 0
     a.dtype = _DTYPES[dt]
+    a.fast_scale = 1 if fast_scale else 0
     with torch.cuda.device(dev):
         _lib.check(lib.sfa_prefill_fwd(ctypes.byref(a), _stream_ptr(dev)))
     return (out, lse) if return_lse else out

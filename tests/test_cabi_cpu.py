@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
         names = [re.search(r"(\w+)(\[\d+\])?\s*$", d.strip()).group(1) for d in body.split(";") if d.strip()]
         assert names == [f[0] for f in cls._fields_], cname
     assert ctypes.sizeof(_lib.DecodeArgs) == 10 * 8 + 12 * 4 + 8 + 8 + 8 + 8 + 8 + 8  # + kv_layout, page_size | table | stride, pages | heads_kv
-    assert ctypes.sizeof(_lib.PrefillArgs) == 5 * 8 + 6 * 4 + 12 * 8 + 3 * 4 + 4 - 0
+    assert ctypes.sizeof(_lib.PrefillArgs) == 5 * 8 + 6 * 4 + 12 * 8 + 4 * 4
 
 
 def test_argument_validation_without_gpu(lib):
