@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""In-process A/B of the prefill kernel generations at the headline shape (interleaved rounds,
+"""In-process A/B of the prefill kernels at the headline shape (interleaved rounds; impl numbers:
+prefill_dispatch.hip -- 0 baseline, 1 default (exact scale), 3 prescaled Q, 10 exact forced, 20-22 128-row,
+30-32 16x16x32;
 cdna_hip_programming.md rule 24).  usage: python tools/prefill_ab.py [impl ...] [--noncausal] [--d64]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
