@@ -40,10 +40,15 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // flash_api.cpp:38, flash_attn.cu:1024).  Each workgroup is 4 waves on one (b,h,split); aim
 // for >= 4 workgroups per CU (1024 on 256 CUs) but keep >= 256 cached rows per workgroup so
 // every wave still streams >= 64 rows.
+// Split count for num_splits <= 0.  Measured on MI355X (tools/decode_small.py, fp16 D=128): splitting
+// pays only while B*H alone leaves most CUs without a workgroup -- B=1 H=32 M=8192: 72.8 us unsplit,
+// 29.1 us at 4-8 splits, 35.7 at 32; B=2: 74.2 -> 46.8 at 2 splits, 52.0 at 16; from B*H >= 256 on one
+// split is best (the combine kernel and the partials cost ~3 us).  Aim for ~128 workgroups, and keep
+// every split at least 2048 cache rows long.
 static int auto_splits(int B, int H, int /*D*/, int M) {
     const long long bh = (long long)B * H;
-    long long s = (1024 + bh - 1) / bh;
-    const long long cap = M / 256 > 1 ? M / 256 : 1;
+    long long s = (128 + bh - 1) / bh;
+    const long long cap = M / 2048 > 1 ? M / 2048 : 1;
     if (s > cap) s = cap;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
