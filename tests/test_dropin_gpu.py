@@ -166,3 +166,51 @@ def test_entry_points_are_graph_capturable():
     work()
     torch.cuda.synchronize()
     assert torch.equal(o, o_g) and torch.equal(po, po_g) and torch.equal(kc, kc_g)
+
+
+@pytest.mark.parametrize("layout", ["blmhd", "blhmd", "paged"])
+def test_prefill_and_decode_agree(layout):
+    """The two hot paths against each other: the last row of a causal prefill over S tokens equals a
+    decode step for token S-1 on a cache holding tokens 0..S-2 (RoPE off), in every cache layout; and the
+    row the decode step appends is token S-1's K/V."""
+    import starflashattention_amd as sfa
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    B, H, S, D, M, ps = 3, 4, 333, 128, 512, 16
+    tdt = torch.bfloat16
+    q, k, v = (torch.randn(B, H, S, D, device=dev).to(tdt) for _ in range(3))
+    o_prefill = sfa.flash_attn_fwd(q, k, v, causal=True)
+    kc = torch.zeros(B, 1, M, H, D, device=dev, dtype=tdt)
+    vc = torch.zeros_like(kc)
+    kc[:, 0, :S - 1] = k[:, :, :S - 1].transpose(1, 2)
+    vc[:, 0, :S - 1] = v[:, :, :S - 1].transpose(1, 2)
+    qkv = torch.stack([q[:, :, S - 1], k[:, :, S - 1], v[:, :, S - 1]], 1).contiguous()
+    sl = torch.full((B,), S - 1, dtype=torch.int32, device=dev)
+    o = torch.empty(B, H, D, device=dev, dtype=tdt)
+    z = torch.zeros(0, dtype=tdt, device=dev)
+    kw = {}
+    if layout == "blhmd":
+        kc, vc = (t.permute(0, 1, 3, 2, 4).contiguous() for t in (kc, vc))
+        kw["kv_layout"] = "blhmd"
+    elif layout == "paged":
+        pps = M // ps
+        table = torch.randperm(B * pps, device=dev).to(torch.int32).view(B, pps)
+        def to_pool(c):
+            pool = torch.zeros(B * pps, 1, ps, H, D, device=dev, dtype=tdt)
+            pool[table.long().view(-1)] = c.view(B, 1, pps, ps, H, D).permute(0, 2, 1, 3, 4, 5).reshape(B * pps, 1, ps, H, D)
+            return pool
+        kc, vc = to_pool(kc), to_pool(vc)
+        kw.update(kv_layout="paged", block_table=table)
+    sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, 0, M, 1, 0, **kw)
+    sfa.check_decode_status()
+    np.testing.assert_allclose(o.float().cpu().numpy(), o_prefill[:, :, S - 1].float().cpu().numpy(),
+                               atol=1.6e-2, rtol=1.6e-2)
+    pos = S - 1
+    for b in range(B):
+        if layout == "blmhd":
+            row_k = kc[b, 0, pos]
+        elif layout == "blhmd":
+            row_k = kc[b, 0, :, pos]
+        else:
+            row_k = kc[int(table[b, pos // ps]), 0, pos % ps]
+        assert torch.equal(row_k, k[b, :, pos])
