@@ -25,7 +25,7 @@ ARCH = "gfx950"
 
 EXTRA_FLAGS = {}      # per-source extra hipcc flags (none needed at present)
 
-KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "prefill_kernel.hip", "prefill_kernel16.hip", "prefill_kernel_bm128.hip", "prefill_baseline.hip", "prefill_dispatch.hip",
+KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_kernel.hip", "prefill_kernel16.hip", "prefill_kernel_bm128.hip", "prefill_baseline.hip", "prefill_dispatch.hip",
                   "aux_kernels.hip", "c_api.hip", "cxx_surface.hip"]
 
 

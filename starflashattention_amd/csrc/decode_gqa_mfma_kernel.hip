@@ -1,0 +1,343 @@
+// Grouped-query decode on the matrix cores, for groups too large for the VALU kernel
+// (decode_gqa_kernel.hip is VALU-bound from 8 query heads per kv head on: 4.1 of 6.5 TB/s).
+// One workgroup per (batch, kv head, split), four waves, each wave walks its share of the cached rows
+// in 32-key tiles with the fragment maps of prefill_core16.h (v_mfma_f32_16x16x32, 16 query columns of
+// which G are real):
+//   S^T[key][q] = K . Q^T     A = K rows, read from HBM DIRECTLY in operand layout: lane (c = l & 15,
+//                                 g = l >> 4) loads K[t + 16kt + c][32ks + 8g .. +8] -- 16 B, every byte of
+//                                 the 32 x 256-B tile fetched exactly once;
+//                             B = Q^T held in registers for the whole kernel (re-laid out once through LDS);
+//   O^T[d][q] += V^T . P^T    P^T = the exponentiated S^T accumulators, packed (no data movement);
+//                             V^T through a wave-private LDS tile: row-major ds_write_b128 in, ds_read_b64_tr_b16
+//                             out (no barrier: a wave's LDS operations execute in order).
+// The query sits on the lane in both accumulators: one online-softmax state per lane, row max across the
+// four 16-lane groups by v_permlane32_swap + v_permlane16_swap.  Scores are scaled in fp32 (exact).
+// The new token is one more tile of one valid key whose K/V come from the prologue's registers.
+// Per 32 keys a wave issues 16 MFMAs and ~60 VALU instructions for 16 KB of cache: HBM-bound for any G <= 16.
+#include <cstdlib>
+
+#include "decode_common.h"
+#include "prefill_core16.h"
+
+namespace sfa {
+
+namespace {
+
+using namespace decode;
+using prefill::Mfma16;
+using prefill::quad_max;
+using prefill::quad_sum;
+using prefill::lds_i16x4;
+
+constexpr int kTile = 32;                       // keys per tile
+
+template <class Tr, int G, bool NT>
+__global__ void __launch_bounds__(kDecodeWaves * 64)
+decode_gqa_mfma_kernel(const DecodeKernelParams p) {
+    constexpr int D = 128, W = kDecodeWaves;
+    constexpr int NKS = D / 32;                 // k-steps of a QK^T accumulator
+    constexpr int NDT = D / 16;                 // 16-wide d tiles of O^T
+    constexpr int VS = 2 * D + 32;              // LDS row stride of the V tile (conflict-free transposed reads)
+    constexpr int VTILE = kTile * VS;
+    using Vec = typename Tr::mfma_vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int hk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;     // MFMA lane coordinates
+    const int sub = lane & 15;                  // prologue / epilogue: which 8 dims (same 16-lane split)
+    const int S = p.num_splits;
+    const int Hq = p.H, Hkv = p.Hkv;
+
+    const int pos = p.seq_len[b];
+    if (pos < 0 || pos >= p.M) {                // same contract as decode_kernel: poison, flag, touch nothing
+        if (split == 0) {
+            for (int i = tid; i < G * D; i += W * 64)
+                p.o[((long long)b * Hq + (long long)hk * G) * D + i] = Tr::id == 0 ? 0x7e00 : 0x7fc0;
+            if (tid == 0 && hk == 0) atomicOr(p.status, 1);
+        }
+        return;
+    }
+
+    // wave-private LDS: two V tiles; the first also serves the Q / k_new re-layout and the final merge
+    char *const vbuf = smem + wave * 2 * VTILE;
+
+    // ---- prologue (every wave, simple layout: lane `sub` owns dims 8 sub .. +8; lane group g handles
+    // query heads g, g + 4, ...): bias, RoPE (fp32), round to storage, park in LDS in [head][d] order ----
+    const long long row0 = (long long)b * p.qkv_stride + sub * 8;
+    float cs[4], sn[4];
+    const int rot = p.rot_dim;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pj = sub * 4 + i;
+        cs[i] = 1.f; sn[i] = 0.f;
+        if (2 * pj < rot) {
+            if (p.cos_tab) {
+                const long long ti = (long long)pos * (rot >> 1) + pj;
+                cs[i] = Tr::to_f32(p.cos_tab[ti]);
+                sn[i] = Tr::to_f32(p.sin_tab[ti]);
+            } else {                            // same fp32 recipe as decode_kernel.hip
+                const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * pj) / (float)rot);
+                sincosf((float)pos * inv_freq, &sn[i], &cs[i]);
+            }
+        }
+    }
+    auto rope = [&](float (&x)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = x[2 * i], bb = x[2 * i + 1];
+            x[2 * i] = a * cs[i] - bb * sn[i];
+            x[2 * i + 1] = bb * cs[i] + a * sn[i];
+        }
+    };
+    uint16_t *const qs = reinterpret_cast<uint16_t *>(vbuf);            // [16][D] query rows (rows >= G zero)
+    uint16_t *const kn = qs + 16 * D;                                   // [D] the new token's key
+    for (int q = g; q < 16; q += 4) {
+        uint4 pk = make_uint4(0, 0, 0, 0);
+        if (q < G) {
+            float x[8];
+            unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.qkv + row0 + (long long)(hk * G + q) * D), x);
+            if (p.q_bias) {
+                float t[8];
+                unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.q_bias + (long long)(hk * G + q) * D + sub * 8), t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += t[j];
+            }
+            rope(x);
+            pk = pack8<Tr>(x);
+        }
+        *reinterpret_cast<uint4 *>(qs + q * D + sub * 8) = pk;
+    }
+    uint4 kpk = make_uint4(0, 0, 0, 0), vpk = make_uint4(0, 0, 0, 0);
+    {
+        float xk[8], xv[8];
+        unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.qkv + row0 + (long long)(Hq + hk) * D), xk);
+        const uint4 v_raw = *reinterpret_cast<const uint4 *>(p.qkv + row0 + (long long)(Hq + Hkv + hk) * D);
+        vpk = v_raw;
+        if (p.k_bias) {
+            float t[8]; unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.k_bias + (long long)hk * D + sub * 8), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xk[j] += t[j];
+        }
+        if (p.v_bias) {
+            float t[8]; unpack8<Tr>(*reinterpret_cast<const uint4 *>(p.v_bias + (long long)hk * D + sub * 8), t);
+            unpack8<Tr>(v_raw, xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] += t[j];
+            vpk = pack8<Tr>(xv);
+        }
+        rope(xk);
+        kpk = pack8<Tr>(xk);
+        if (g == 0) *reinterpret_cast<uint4 *>(kn + sub * 8) = kpk;
+    }
+    // Q^T fragments (B operand): lane holds Q[q = c][32 ks + 8 g .. +8]
+    Vec qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qs + c * D + 32 * ks + 8 * g));
+    // K fragments of the new-token tile: key 0 of the tile = k_new (lanes c == 0), everything else masked
+    uint4 knf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) knf[ks] = *reinterpret_cast<const uint4 *>(kn + 32 * ks + 8 * g);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the region is reused as a V tile below
+
+    // ---- this wave's slice of the cached rows [0, pos) ----
+    const int rows_per_split = (pos + S - 1) / S;
+    const int r0 = min(pos, split * rows_per_split);
+    const int r1 = min(pos, r0 + rows_per_split);
+    int per_wave = (r1 - r0 + W - 1) / W;
+    per_wave = (per_wave + kTile - 1) / kTile * kTile;
+    const int w0 = min(r1, r0 + wave * per_wave);
+    const int w1 = min(r1, w0 + per_wave);
+
+    const long long rs = p.kv_row_stride;
+    const long long head_base = ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride;
+    const uint16_t *const kb = p.k_cache + head_base + 8 * g;          // + row * rs + 32 ks: operand layout
+    const uint16_t *const vb = p.v_cache + head_base + 8 * (lane & 15);    // + row * rs: row-major chunks
+
+    f32x4 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] = 0.f;
+    float m = neg_inf(), l = 0.f;               // per lane: query c (replicated over the 4 lane groups)
+
+    auto load_k = [&](uint4 (&kk)[2][NKS], int t) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int row = min(t + 16 * kt + c, w1 - 1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) kk[kt][ks] = ld16<NT>(kb + (long long)row * rs + 32 * ks);
+        }
+    };
+    auto load_v = [&](uint4 (&vv)[8], int t) {          // lane: rows (lane >> 4) + 4 i, chunk lane & 15
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = min(t + (lane >> 4) + 4 * i, w1 - 1);
+            vv[i] = ld16<NT>(vb + (long long)row * rs);
+        }
+    };
+    auto store_v = [&](const uint4 (&vv)[8], char *buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint4 *>(buf + VS * ((lane >> 4) + 4 * i) + 16 * (lane & 15)) = vv[i];
+    };
+    // one 32-key tile: kk = K fragments, V tile at buf, keys [t, t + nvalid) are real
+    auto tile = [&](const uint4 (&kk)[2][NKS], const char *buf, int nvalid) {
+        f32x4 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) s[kt] = Mfma16<Tr>::run(bitcast<Vec>(kk[kt][ks]), qf[ks], s[kt]);
+        }
+        float mx = neg_inf();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {       // element r of tile kt = key 16 kt + 4 g + r
+                s[kt][r] = (16 * kt + 4 * g + r < nvalid) ? s[kt][r] * p.scale_log2 : neg_inf();
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = fmaxf(m, quad_max(mx));
+        const float ms = (mx == neg_inf()) ? 0.f : mx;
+        const float alpha = fast_exp2(m - ms);
+        m = mx;
+        l *= alpha;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
+        uint32_t pb[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const float p0 = fast_exp2(s[kt][0] - ms), p1 = fast_exp2(s[kt][1] - ms);
+            const float p2 = fast_exp2(s[kt][2] - ms), p3 = fast_exp2(s[kt][3] - ms);
+            l += (p0 + p1) + (p2 + p3);
+            pb[2 * kt] = Tr::pack2(p0, p1);
+            pb[2 * kt + 1] = Tr::pack2(p2, p3);
+        }
+        const Vec pv = bitcast<Vec>(make_uint4(pb[0], pb[1], pb[2], pb[3]));
+        // V^T fragments: lane (c, g) reads rows 4 g + (c >> 2) and 16 + ..., 8 bytes at column 16 dt + 4 (c & 3)
+        const char *vr = buf + VS * (4 * g + (c >> 2)) + 8 * (c & 3);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const auto t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vr + 32 * dt));
+            const auto t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vr + VS * 16 + 32 * dt));
+            u32x4 av;
+            const u32x2 a_lo = bitcast<u32x2>(t0), a_hi = bitcast<u32x2>(t1);
+            av[0] = a_lo[0]; av[1] = a_lo[1]; av[2] = a_hi[0]; av[3] = a_hi[1];
+            o[dt] = Mfma16<Tr>::run(bitcast<Vec>(av), pv, o[dt]);
+        }
+    };
+
+    if (w0 < w1) {
+        uint4 ka[2][NKS], kb2[2][NKS], vr[8];
+        load_k(ka, w0);
+        load_v(vr, w0);
+        for (int t = w0; t < w1; t += 2 * kTile) {
+            store_v(vr, vbuf);
+            const bool more1 = t + kTile < w1;
+            if (more1) { load_k(kb2, t + kTile); load_v(vr, t + kTile); }
+            tile(ka, vbuf, w1 - t);
+            if (more1) {
+                store_v(vr, vbuf + VTILE);
+                if (t + 2 * kTile < w1) { load_k(ka, t + 2 * kTile); load_v(vr, t + 2 * kTile); }
+                tile(kb2, vbuf + VTILE, w1 - t - kTile);
+            }
+        }
+    }
+
+    // ---- the new token (position `pos`): last split, wave 0 -- a tile with one real key ----
+    if (split == S - 1 && wave == 0) {
+        {   // every row of the V tile = v_new (rows 1.. get weight 0, but 0 * stale LDS bits could be NaN)
+            uint4 vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[i] = vpk;
+            store_v(vv, vbuf);
+        }
+        uint4 kk[2][NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kk[0][ks] = knf[ks];                // only the lanes with c == 0 matter (key 0); the rest is masked
+            kk[1][ks] = make_uint4(0, 0, 0, 0);
+        }
+        tile(kk, vbuf, 1);
+        if (g == 0) {                           // append: 16 lanes x 16 B = one row each
+            const long long roff = head_base + (long long)pos * rs + sub * 8;
+            *reinterpret_cast<uint4 *>(p.k_cache + roff) = kpk;
+            *reinterpret_cast<uint4 *>(p.v_cache + roff) = vpk;
+        }
+    }
+
+    // ---- merge the workgroup's waves through LDS (after every wave is done with its V tiles) ----
+    const float ltot = quad_sum(l);             // the four lane groups hold disjoint keys of query c
+    __syncthreads();
+    float *const red = reinterpret_cast<float *>(smem);                 // [W][G][D + 2]
+    if (c < G) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * G + c) * (D + 2) + 16 * dt + 4 * g + r] = o[dt][r];
+        if (g == 0) { red[(wave * G + c) * (D + 2) + D] = m; red[(wave * G + c) * (D + 2) + D + 1] = ltot; }
+    }
+    __syncthreads();
+    if (tid < 16 * G) {
+        const int q = tid / 16, sb = tid % 16;
+        Stream tot;
+        tot.init();
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const float *rw = red + (w * G + q) * (D + 2);
+            float a2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2[j] = rw[sb * 8 + j];
+            tot.merge(rw[D], rw[D + 1], a2);
+        }
+        const long long bh = (long long)b * Hq + hk * G + q;
+        if (S == 1) {
+            const float inv = 1.0f / tot.l;          // l >= 1: the new token is always present
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = tot.acc[j] * inv;
+            *reinterpret_cast<uint4 *>(p.o + bh * D + sb * 8) = pack8<Tr>(y);
+        } else {
+            float *po = p.part_o + (bh * S + split) * D + sb * 8;
+            *reinterpret_cast<float4 *>(po) = make_float4(tot.acc[0], tot.acc[1], tot.acc[2], tot.acc[3]);
+            *reinterpret_cast<float4 *>(po + 4) = make_float4(tot.acc[4], tot.acc[5], tot.acc[6], tot.acc[7]);
+            if (sb == 0) p.part_ml[bh * S + split] = make_float2(tot.m, tot.l);
+        }
+    }
+}
+
+template <class Tr, int G>
+int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
+    dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
+    constexpr int lds = kDecodeWaves * 2 * kTile * (2 * 128 + 32);      // two V tiles per wave: 73,728 B
+    static_assert(lds >= kDecodeWaves * G * (128 + 2) * 4, "merge area fits");
+    bool nt = 4ll * p.B * p.L * p.M * p.Hkv * 128 > (256ll << 20);      // see decode_kernel.hip
+    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    if (nt) hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, false>), grid, block, lds, stream, p);
+    return check_launch("decode_gqa_mfma_kernel");
+}
+
+}  // namespace
+
+// head_dim 128, contiguous cache layouts, 8 query heads per kv head
+int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
+    if (dtype == SFA_DTYPE_FP16) return launch_g<Fp16, 8>(p, stream);
+    return launch_g<Bf16, 8>(p, stream);
+}
+
+}  // namespace sfa
