@@ -3,9 +3,10 @@
 // One workgroup per (batch, kv head, split), four waves, each wave walks its share of the cached rows
 // in 32-key tiles with the fragment maps of prefill_core16.h (v_mfma_f32_16x16x32, 16 query columns of
 // which G are real):
-//   S^T[key][q] = K . Q^T     A = K rows, read from HBM DIRECTLY in operand layout: lane (c = l & 15,
-//                                 g = l >> 4) loads K[t + 16kt + c][32ks + 8g .. +8] -- 16 B, every byte of
-//                                 the 32 x 256-B tile fetched exactly once;
+//   S^T[key][q] = K . Q^T     A = K rows: head-major caches are read from HBM DIRECTLY in operand layout
+//                                 (lane (c = l & 15, g = l >> 4) loads K[t + 16kt + c][32ks + 8g .. +8]);
+//                                 the reference layout is read row-major and re-laid out through a
+//                                 wave-private LDS tile (64-B pieces of strided rows cost 8 %);
 //                             B = Q^T held in registers for the whole kernel (re-laid out once through LDS);
 //   O^T[d][q] += V^T . P^T    P^T = the exponentiated S^T accumulators, packed (no data movement);
 //                             V^T through a wave-private LDS tile: row-major ds_write_b128 in, ds_read_b64_tr_b16
@@ -31,7 +32,7 @@ using prefill::lds_i16x4;
 
 constexpr int kTile = 32;                       // keys per tile
 
-template <class Tr, int G, bool NT>
+template <class Tr, int G, bool NT, bool KLDS>
 __global__ void __launch_bounds__(kDecodeWaves * 64)
 decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     constexpr int D = 128, W = kDecodeWaves;
@@ -39,6 +40,9 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     constexpr int NDT = D / 16;                 // 16-wide d tiles of O^T
     constexpr int VS = 2 * D + 32;              // LDS row stride of the V tile (conflict-free transposed reads)
     constexpr int VTILE = kTile * VS;
+    constexpr int KS = 2 * D + 16;              // LDS row stride of the K tile (KLDS)
+    constexpr int KTILE = kTile * KS;
+    constexpr int WAVE_LDS = VTILE + KTILE;     // one tile of each: the next tile waits in registers
     using Vec = typename Tr::mfma_vec;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -59,8 +63,9 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         return;
     }
 
-    // wave-private LDS: two V tiles; the first also serves the Q / k_new re-layout and the final merge
-    char *const vbuf = smem + wave * 2 * VTILE;
+    // wave-private LDS: a V tile (also the Q / k_new re-layout area) and a K tile
+    char *const vbuf = smem + wave * WAVE_LDS;
+    char *const kbuf = vbuf + VTILE;
 
     // ---- prologue (every wave, simple layout: lane `sub` owns dims 8 sub .. +8; lane group g handles
     // query heads g, g + 4, ...): bias, RoPE (fp32), round to storage, park in LDS in [head][d] order ----
@@ -166,7 +171,14 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         for (int kt = 0; kt < 2; ++kt) {
             const int row = min(t + 16 * kt + c, w1 - 1);
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kk[kt][ks] = ld16<NT>(kb + (long long)row * rs + 32 * ks);
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (KLDS) {     // row-major like V (256-B rows): rows 16 kt + 4 ks + (lane >> 4), chunk lane & 15
+                    const int r2 = min(t + 16 * kt + 4 * ks + (lane >> 4), w1 - 1);
+                    kk[kt][ks] = ld16<NT>(p.k_cache + head_base + (long long)r2 * rs + 8 * (lane & 15));
+                } else {        // directly in operand layout: 64-B pieces of 16 rows
+                    kk[kt][ks] = ld16<NT>(kb + (long long)row * rs + 32 * ks);
+                }
+            }
         }
     };
     auto load_v = [&](uint4 (&vv)[8], int t) {          // lane: rows (lane >> 4) + 4 i, chunk lane & 15
@@ -180,6 +192,20 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             *reinterpret_cast<uint4 *>(buf + VS * ((lane >> 4) + 4 * i) + 16 * (lane & 15)) = vv[i];
+    };
+    // KLDS: the K tile came in row-major; lay it out as MFMA operands through the wave's LDS K tile
+    auto to_operand = [&](uint4 (&kk)[2][NKS]) {
+        if (!KLDS) return;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                *reinterpret_cast<uint4 *>(kbuf + KS * (16 * kt + 4 * ks + (lane >> 4)) + 16 * (lane & 15)) = kk[kt][ks];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                kk[kt][ks] = *reinterpret_cast<const uint4 *>(kbuf + KS * (16 * kt + c) + 64 * ks + 16 * g);
     };
     // one 32-key tile: kk = K fragments, V tile at buf, keys [t, t + nvalid) are real
     auto tile = [&](const uint4 (&kk)[2][NKS], const char *buf, int nvalid) {
@@ -234,18 +260,22 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     };
 
     if (w0 < w1) {
+        // tile t+1 is in flight into registers while tile t is computed; the LDS tiles are single: a wave's
+        // LDS operations execute in order, so storing tile t+1 cannot overtake the reads of tile t
         uint4 ka[2][NKS], kb2[2][NKS], vr[8];
         load_k(ka, w0);
         load_v(vr, w0);
         for (int t = w0; t < w1; t += 2 * kTile) {
             store_v(vr, vbuf);
+            to_operand(ka);
             const bool more1 = t + kTile < w1;
             if (more1) { load_k(kb2, t + kTile); load_v(vr, t + kTile); }
             tile(ka, vbuf, w1 - t);
             if (more1) {
-                store_v(vr, vbuf + VTILE);
+                store_v(vr, vbuf);
+                to_operand(kb2);
                 if (t + 2 * kTile < w1) { load_k(ka, t + 2 * kTile); load_v(vr, t + 2 * kTile); }
-                tile(kb2, vbuf + VTILE, w1 - t - kTile);
+                tile(kb2, vbuf, w1 - t - kTile);
             }
         }
     }
@@ -312,32 +342,39 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     }
 }
 
-template <class Tr, int G>
-int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
+template <class Tr, int G, bool NT, bool KLDS>
+int launch_k(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
-    constexpr int lds = kDecodeWaves * 2 * kTile * (2 * 128 + 32);      // two V tiles per wave: 73,728 B
+    constexpr int lds = kDecodeWaves * kTile * ((2 * 128 + 32) + (2 * 128 + 16));       // 71,680 B
     static_assert(lds >= kDecodeWaves * G * (128 + 2) * 4, "merge area fits");
-    bool nt = 4ll * p.B * p.L * p.M * p.Hkv * 128 > (256ll << 20);      // see decode_kernel.hip
-    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
-    static bool attr_set = false;
+    static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (nt) hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, true>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, false>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, NT, KLDS>), grid, block, lds, stream, p);
     return check_launch("decode_gqa_mfma_kernel");
+}
+
+template <class Tr, int G>
+int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
+    bool nt = 4ll * p.B * p.L * p.M * p.Hkv * 128 > (256ll << 20);      // see decode_kernel.hip
+    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+    // Reference layout: a K row of this head is a 256-B segment H*D*2 bytes from the next, and fetching it
+    // as 64-B operand pieces costs 8 % (5.96 vs 6.44 TB/s): load row-major, re-lay out through LDS.
+    // Head-major caches are contiguous, the operand-layout loads go straight to registers (6.7 TB/s).
+    const bool klds = p.kv_row_stride != 128;
+    if (klds) return nt ? launch_k<Tr, G, true, true>(p, stream) : launch_k<Tr, G, false, true>(p, stream);
+    return nt ? launch_k<Tr, G, true, false>(p, stream) : launch_k<Tr, G, false, false>(p, stream);
 }
 
 }  // namespace
 
-// head_dim 128, contiguous cache layouts, 8 query heads per kv head
+// head_dim 128, contiguous cache layouts, 4 or 8 query heads per kv head
 int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
-    if (dtype == SFA_DTYPE_FP16) return launch_g<Fp16, 8>(p, stream);
-    return launch_g<Bf16, 8>(p, stream);
+    if (p.H == 4 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 4>(p, stream) : launch_g<Bf16, 4>(p, stream);
+    return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 8>(p, stream) : launch_g<Bf16, 8>(p, stream);
 }
 
 }  // namespace sfa

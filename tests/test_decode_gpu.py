@@ -362,7 +362,7 @@ def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
 @pytest.mark.parametrize("num_splits", [0, 1, 3])
 def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     """Grouped-query decode (num_heads_kv): one workgroup serves the G query heads of a
-    kv head from one pass over the cache (G = 8, D = 128, contiguous caches: the matrix-core kernel).  Checked against the (oracle-validated) multi-head kernel on
+    kv head from one pass over the cache (G >= 4, D = 128, contiguous caches: the matrix-core kernel).  Checked against the (oracle-validated) multi-head kernel on
     the expanded problem -- kv heads repeated G times -- and against the fp64 oracle on it."""
     rng = np.random.default_rng(11)
     B, Hkv, L, M, layer = 3, 2, 2, 160, 0
@@ -418,9 +418,9 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     sfa.flash_decode(qkv, qb, kb_, vb_, kp, vp, sl, o_p, B, M, H, D, rot, M, L, layer, num_splits=num_splits,
                      num_heads_kv=Hkv, kv_layout="paged", block_table=table)
     sfa.check_decode_status()
-    if D >= 128 and not (group == 8 and D == 128):
+    if D >= 128 and not (group >= 4 and D == 128):
         assert torch.equal(o_p, o)
-    else:   # D=64 pages in shorter steps; G=8 D=128 contiguous runs on the matrix cores, paged on the VALU kernel
+    else:   # D=64 pages in shorter steps; G>=4 D=128 contiguous runs on the matrix cores, paged on the VALU kernel
         np.testing.assert_allclose(o_p.float().cpu().numpy(), o.float().cpu().numpy(), atol=tol / 2, rtol=tol / 2)
     for b in range(B):
         pg, row = int(table[b, lens[b] // ps]), lens[b] % ps
