@@ -32,7 +32,7 @@ using prefill::lds_i16x4;
 
 constexpr int kTile = 32;                       // keys per tile
 
-template <class Tr, int G, bool NT, bool KLDS>
+template <class Tr, int G, bool NT, bool KLDS, bool PAGED = false>
 __global__ void __launch_bounds__(kDecodeWaves * 64)
 decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     constexpr int D = 128, W = kDecodeWaves;
@@ -146,16 +146,43 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the region is reused as a V tile below
 
     // ---- this wave's slice of the cached rows [0, pos) ----
-    const int rows_per_split = (pos + S - 1) / S;
+    int rows_per_split = (pos + S - 1) / S;
+    rows_per_split = (rows_per_split + kTile - 1) / kTile * kTile;     // paged: tiles never straddle 16-row halves
     const int r0 = min(pos, split * rows_per_split);
     const int r1 = min(pos, r0 + rows_per_split);
     int per_wave = (r1 - r0 + W - 1) / W;
     per_wave = (per_wave + kTile - 1) / kTile * kTile;
-    const int w0 = min(r1, r0 + wave * per_wave);
-    const int w1 = min(r1, w0 + per_wave);
+    const int w0 = __builtin_amdgcn_readfirstlane(min(r1, r0 + wave * per_wave));   // wave-uniform
+    const int w1 = __builtin_amdgcn_readfirstlane(min(r1, w0 + per_wave));
 
     const long long rs = p.kv_row_stride;
-    const long long head_base = ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride;
+    // paged (always with KLDS): split and wave boundaries are multiples of 32 rows, so the rows 0-15 and
+    // 16-31 of a tile each lie in ONE page (page_size >= 16): two scalar table look-ups per tile and a
+    // compile-time choice per load, no per-lane select.  Rows past the wave's end are clamped to its last
+    // row; clamping the page INDEX the same way keeps their address on that row.
+    const long long head_base = PAGED ? (long long)p.layer * (rs << p.page_shift) + (long long)hk * p.kv_head_stride
+                                      : ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride;
+    const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;
+    const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    auto page_of = [&](int idx) -> long long {
+        int pg = tbl[idx];
+        if ((unsigned)pg >= (unsigned)p.num_pages) {
+            if (tid == 0) atomicOr(p.status, 2);
+            pg = 0;
+        }
+        return pg * p.page_stride;
+    };
+    long long po[2] = {0, 0};                   // element offsets of the pages of the tile being loaded
+    auto set_pages = [&](int t) {
+        if (!PAGED) return;
+        const int last = (w1 - 1) >> p.page_shift;
+        po[0] = page_of(min(t >> p.page_shift, last));
+        po[1] = page_of(min((t + 16) >> p.page_shift, last));
+    };
+    auto row_off = [&](int row, int half) -> long long {
+        if (!PAGED) return (long long)row * rs;
+        return po[half] + (long long)(row & pmask) * rs;
+    };
     const uint16_t *const kb = p.k_cache + head_base + 8 * g;          // + row * rs + 32 ks: operand layout
     const uint16_t *const vb = p.v_cache + head_base + 8 * (lane & 15);    // + row * rs: row-major chunks
 
@@ -167,6 +194,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     float m = neg_inf(), l = 0.f;               // per lane: query c (replicated over the 4 lane groups)
 
     auto load_k = [&](uint4 (&kk)[2][NKS], int t) {
+        set_pages(t);                           // load_v(.., t) follows and uses the same pages
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int row = min(t + 16 * kt + c, w1 - 1);
@@ -174,7 +202,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
             for (int ks = 0; ks < NKS; ++ks) {
                 if (KLDS) {     // row-major like V (256-B rows): rows 16 kt + 4 ks + (lane >> 4), chunk lane & 15
                     const int r2 = min(t + 16 * kt + 4 * ks + (lane >> 4), w1 - 1);
-                    kk[kt][ks] = ld16<NT>(p.k_cache + head_base + (long long)r2 * rs + 8 * (lane & 15));
+                    kk[kt][ks] = ld16<NT>(p.k_cache + head_base + row_off(r2, kt) + 8 * (lane & 15));
                 } else {        // directly in operand layout: 64-B pieces of 16 rows
                     kk[kt][ks] = ld16<NT>(kb + (long long)row * rs + 32 * ks);
                 }
@@ -185,7 +213,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = min(t + (lane >> 4) + 4 * i, w1 - 1);
-            vv[i] = ld16<NT>(vb + (long long)row * rs);
+            vv[i] = ld16<NT>(vb + row_off(row, i >> 2));
         }
     };
     auto store_v = [&](const uint4 (&vv)[8], char *buf) {
@@ -296,7 +324,8 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         }
         tile(kk, vbuf, 1);
         if (g == 0) {                           // append: 16 lanes x 16 B = one row each
-            const long long roff = head_base + (long long)pos * rs + sub * 8;
+            long long roff = head_base + (long long)pos * rs + sub * 8;
+            if (PAGED) roff = head_base + page_of(pos >> p.page_shift) + (long long)(pos & pmask) * rs + sub * 8;
             *reinterpret_cast<uint4 *>(p.k_cache + roff) = kpk;
             *reinterpret_cast<uint4 *>(p.v_cache + roff) = vpk;
         }
@@ -342,18 +371,18 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     }
 }
 
-template <class Tr, int G, bool NT, bool KLDS>
+template <class Tr, int G, bool NT, bool KLDS, bool PAGED = false>
 int launch_k(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
     constexpr int lds = kDecodeWaves * kTile * ((2 * 128 + 32) + (2 * 128 + 16));       // 71,680 B
     static_assert(lds >= kDecodeWaves * G * (128 + 2) * 4, "merge area fits");
     static bool attr_set = false;       // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, NT, KLDS>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>), grid, block, lds, stream, p);
     return check_launch("decode_gqa_mfma_kernel");
 }
 
@@ -364,6 +393,8 @@ int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
     // Reference layout: a K row of this head is a 256-B segment H*D*2 bytes from the next, and fetching it
     // as 64-B operand pieces costs 8 % (5.96 vs 6.44 TB/s): load row-major, re-lay out through LDS.
     // Head-major caches are contiguous, the operand-layout loads go straight to registers (6.7 TB/s).
+    if (p.block_table)
+        return nt ? launch_k<Tr, G, true, true, true>(p, stream) : launch_k<Tr, G, false, true, true>(p, stream);
     const bool klds = p.kv_row_stride != 128;
     if (klds) return nt ? launch_k<Tr, G, true, true>(p, stream) : launch_k<Tr, G, false, true>(p, stream);
     return nt ? launch_k<Tr, G, true, false>(p, stream) : launch_k<Tr, G, false, false>(p, stream);
@@ -371,7 +402,7 @@ int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
 
 }  // namespace
 
-// head_dim 128, contiguous cache layouts, 4 or 8 query heads per kv head
+// head_dim 128, any cache layout, 4 or 8 query heads per kv head
 int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
     if (p.H == 4 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 4>(p, stream) : launch_g<Bf16, 4>(p, stream);
     return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 8>(p, stream) : launch_g<Bf16, 8>(p, stream);
