@@ -390,6 +390,10 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     sfa.check_decode_status()
     tol = TOL[dtype]
     np.testing.assert_allclose(o.float().cpu().numpy(), o_x.float().cpu().numpy(), atol=tol / 2, rtol=tol / 2)
+    f = lambda t: t.float().cpu().numpy()
+    ref = decode_ref(f(qkv_x), f(rep(kc, 3)), f(rep(vc, 3)), lens, layer, rot, dtype=dtype, q_bias=f(qb),
+                     k_bias=f(rep(kb_, 0)), v_bias=f(rep(vb_, 0)))
+    np.testing.assert_allclose(f(o), ref["o"], atol=tol, rtol=tol)         # the fp64 oracle on the expanded problem
     if group == 2:          # same row grouping as the multi-head kernel: bit-identical
         assert torch.equal(o, o_x)
     # appended rows: identical to the expanded run's, everything else untouched
