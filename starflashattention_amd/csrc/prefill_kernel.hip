@@ -40,7 +40,7 @@
 //     first tiles).  exp2 arguments stay <= 8, so P <= 256: bf16/fp16 keep the same RELATIVE
 //     precision and the fp32 accumulators have ample headroom.
 //   * Two numeric flavours (template ORD): 2 = exact scale (scores are the fp32 QK^T, one FMA by
-//     scale*log2(e) in front of v_exp; used when the log-sum-exp is returned) and 6 = prescaled Q
+//     scale*log2(e) in front of v_exp; the default) and 6 = prescaled Q
 //     (Q * scale*log2(e) rounded to 16 bit once per q-tile, the first QK^T MFMA of a half-step starts
 //     from C = -reference max, so scores leave the MFMA as exp2 arguments and the scale/subtract pass
 //     is gone: +5 %; opt-in, sfa_prefill_args.fast_scale).  launch_prefill_main picks.
