@@ -153,9 +153,13 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
 #pragma unroll
         for (int i = 0; i < PF; ++i) vf[i] = ld_v(i);
     }
-    if (PS && NKS >= 8 && DO_QK) {    // stage X of pair 0 already in slot 0
+    // which slot a pair's first stage runs in (see the staging note below); PPS pairs share a slot
+    constexpr int PPS = (NKS >= 8) ? 1 : 2;
+    if (PS && (NKS >= 8 || NKS == 4) && DO_QK) {    // stage X of the first pair(s) already in slot 0
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) { sO[q][0] = fast_exp2(sO[q][0]); sO[q][1] = fast_exp2(sO[q][1]); }
+        for (int q = 0; q < NQB; ++q)
+#pragma unroll
+            for (int e = 0; e < 2 * PPS; ++e) sO[q][e] = fast_exp2(sO[q][e]);
     }
     float msafe[NQB] = {};
 #pragma unroll
@@ -200,9 +204,12 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
     // F (scale+subtract), X (v_exp), A (row sum + pack) -- so no instruction sits right behind
     // the one it depends on (fma -> exp -> add/cvt back to back stalls on VALU/TRANS latency).
     // Pair g (elements 2g, 2g+1) does F in soft-slot g, X in g+1, A in g+2; soft-slot u is QK slot
-    // u+1 for u < NKS-1 and PV slot u-(NKS-1) after that.  Needs NKS >= 8 (pairs 0..3 packed before
-    // the first PV MFMA, pairs 4..7 before PV slot NPV/2).
-    constexpr bool STAGED = (ORD == 2 || ORD == 6) && (NKS >= 8) && DO_QK;     // ORD: 0 = plain slices, 2 = staged, 1 = VALU before MFMA (A/B: no gain)
+    // u+1 for u < NKS-1 and PV slot u-(NKS-1) after that (pairs 0..3 must be packed before the first PV
+    // MFMA, pairs 4..7 before PV slot NPV/2).  head_dim 64 has only 3 + 4 such slots: there pairs 0..3
+    // start together in soft-slot 0 and pairs 4..7 in soft-slot 2 (prescaled mode: two pairs per slot).
+    constexpr bool STAGED = (ORD == 2 || ORD == 6) && (NKS >= 8 || NKS == 4) && DO_QK;     // ORD: 0 = plain slices, 2 = staged, 1 = VALU before MFMA (A/B: no gain)
+    auto fslot = [](int g) -> int { return NKS >= 8 ? g : (g < 4 ? 0 : 2); };      // exact mode: slot of stage F
+    auto xslot = [](int g) -> int { return g / PPS; };                             // prescaled mode: slot of stage X
     auto stage_f = [&](int g) {
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -226,15 +233,25 @@ __device__ __forceinline__ void h_block(const char *kb, const char *vb, const ch
         }
     };
     auto staged_slot = [&](int u) {
-        if (PS) {                           // two stages: X in soft-slot g, A in g+1
-            const int w = u + 1;            // (slot 0 already did X of pair 0)
-            if (w - 1 >= 0 && w - 1 < 8) stage_a(w - 1);
-            if (w >= 0 && w < 8) stage_x(w);
+        if (PS) {                           // two stages: X in slot xslot(g), A one slot later
+            const int w = u + 1;            // (slot 0 already did X of the pairs with xslot 0)
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (xslot(g) + 1 == w) stage_a(g);
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (xslot(g) == w) stage_x(g);
             return;
         }
-        if (u - 2 >= 0 && u - 2 < 8) stage_a(u - 2);
-        if (u - 1 >= 0 && u - 1 < 8) stage_x(u - 1);
-        if (u < 8) stage_f(u);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (fslot(g) + 2 == u) stage_a(g);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (fslot(g) + 1 == u) stage_x(g);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (fslot(g) == u) stage_f(g);
     };
 
     if (DO_QK) {
