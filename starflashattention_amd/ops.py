@@ -106,7 +106,8 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         if t is not None:
             _check_gpu_tensor(t, name, dt, (M, int(rotary_embedding_dim) // 2), dev)
     with torch.cuda.device(dev):
-        S = int(num_splits) if num_splits and num_splits > 0 else lib.sfa_decode_auto_splits(B, H, D, M)
+        # grouped queries launch one workgroup per KV head: size the split count by those
+        S = int(num_splits) if num_splits and num_splits > 0 else lib.sfa_decode_auto_splits(B, Hkv, D, M)
         ws = _workspace(dev, lib.sfa_decode_workspace_bytes(B, H, D, M, S))
         a = _lib.DecodeArgs()
         a.qkv = qkv.data_ptr()
