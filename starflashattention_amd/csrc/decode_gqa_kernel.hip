@@ -300,9 +300,9 @@ int launch_t(const DecodeKernelParams &p, hipStream_t stream) {
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
     // 8 query heads per kv head make this kernel VALU-bound (4.1 TB/s): the matrix-core form takes over
     // (head_dim 128; SFA_DECODE_GQA_MFMA=0 keeps the VALU kernel for A/B)
-    if (head_dim == 128 && (p.H == 8 * p.Hkv || p.H == 4 * p.Hkv) && (dtype == SFA_DTYPE_FP16 || dtype == SFA_DTYPE_BF16)) {
+    if (head_dim == 128 && (p.H == 16 * p.Hkv || p.H == 8 * p.Hkv || p.H == 4 * p.Hkv) && (dtype == SFA_DTYPE_FP16 || dtype == SFA_DTYPE_BF16)) {
         const char *e = std::getenv("SFA_DECODE_GQA_MFMA");
-        if (!e || std::atoi(e) != 0) return launch_decode_gqa_mfma(p, dtype, stream);
+        if (!e || std::atoi(e) != 0 || p.H == 16 * p.Hkv) return launch_decode_gqa_mfma(p, dtype, stream);
     }
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_t<Fp16, 128>(p, stream);

@@ -402,8 +402,9 @@ int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
 
 }  // namespace
 
-// head_dim 128, any cache layout, 4 or 8 query heads per kv head
+// head_dim 128, any cache layout, 4, 8 or 16 query heads per kv head
 int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
+    if (p.H == 16 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 16>(p, stream) : launch_g<Bf16, 16>(p, stream);
     if (p.H == 4 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 4>(p, stream) : launch_g<Bf16, 4>(p, stream);
     return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 8>(p, stream) : launch_g<Bf16, 8>(p, stream);
 }

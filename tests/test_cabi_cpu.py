@@ -80,7 +80,7 @@ def test_argument_validation_without_gpu(lib):
     a.kv_layout = _lib.KV_LAYOUTS["blhmd"]
     a.num_heads, a.num_heads_kv = 6, 4
     assert lib.sfa_decode(ctypes.byref(a), None) == -2 and b"num_heads_kv" in lib.sfa_last_error()
-    a.num_heads, a.num_heads_kv = 12, 4                         # group of 3: not in {1, 2, 4, 8}
+    a.num_heads, a.num_heads_kv = 12, 4                         # group of 3: not in {1, 2, 4, 8, 16}
     assert lib.sfa_decode(ctypes.byref(a), None) == -2
     a.num_heads, a.num_heads_kv, a.kv_layout = 8, 4, _lib.KV_LAYOUTS["paged"]
     assert lib.sfa_decode(ctypes.byref(a), None) == -5          # grouped queries over a paged cache: accepted
