@@ -4,10 +4,14 @@
 // known answer instead of printing it, times the steady state with HIP events, and shows that the
 // reference's out-of-range pair (4096, 4096) is rejected instead of overrunning the cache.
 //
+// The timed iterations sit inside a roctx range, as the reference brackets its own with NVTX
+// (examples/cpp/testFlashDecoder.cc:7,99,106): `rocprofv3 --marker-trace -- build/flash_decoder_harness`.
+//
 //   hipcc -O2 -std=c++17 --offload-arch=gfx950 -I. examples/cpp/flash_decoder_harness.cc \
-//         -Lstarflashattention_amd/lib -lStarFlashAttention -o build/flash_decoder_harness
+//         -Lstarflashattention_amd/lib -lStarFlashAttention -L/opt/rocm/lib -lroctx64 -o build/flash_decoder_harness
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <roctracer/roctx.h>
 
 #include <cmath>
 #include <cstdio>
@@ -66,7 +70,9 @@ static int run_case(int B, int H, int D, int M, int seq, int L, int layer, int s
     HIP_OK(hipEventCreate(&e1));
     const int iters = 50;
     HIP_OK(hipEventRecord(e0, stream));
+    roctxRangePushA("run_flash_decoder Range");
     for (int i = 0; i < iters; ++i) run_flash_decoder<half>(in, prm, stream);
+    roctxRangePop();
     HIP_OK(hipEventRecord(e1, stream));
     HIP_OK(hipStreamSynchronize(stream));
     float ms = 0;
@@ -100,6 +106,53 @@ static int run_case(int B, int H, int D, int M, int seq, int L, int layer, int s
     return (bad || rejected) ? 1 : 0;
 }
 
+// Two streams decoding different problems of the same shape at once, num_splits > 1: each stream's split
+// partials must live in its own scratch.  Problem A is all ones (answer 1.0); problem B has qkv = 2 and a
+// V cache of 2 (every value row is 2, so the answer is 2.0 whatever the softmax weights are).
+static int run_two_streams() {
+    const int B = 2, H = 32, D = 128, M = 2048, seq = 2047, L = 1, iters = 200;
+    Flash_decoder_input in[2];
+    Flash_decoder_params prm;
+    prm.kBlockN = 128; prm.num_splits = 4; prm.kNThreads = 32;
+    hipStream_t st[2];
+    const size_t n_qkv = (size_t)B * 3 * H * D, n_o = (size_t)B * H * D, n_cache = (size_t)B * L * M * H * D;
+    std::vector<int> lens(B, seq);
+    for (int i = 0; i < 2; ++i) {
+        Flash_decoder_input &x = in[i];
+        x.batch_size = B; x.num_heads = H; x.head_dim = D; x.head_dim_inv = 1.0f / std::sqrt((float)D);
+        x.memory_max_len = M; x.max_input_length = M; x.rotary_embedding_dim = D; x.stride = 3 * H * D;
+        x.idx_layer = 0; x.num_layer = L;
+        x.rotary_cos_table = nullptr; x.rotary_sin_table = nullptr;
+        HIP_OK(hipMalloc((void **)&x.qkv, n_qkv * sizeof(half)));
+        HIP_OK(hipMalloc((void **)&x.o, n_o * sizeof(half)));
+        HIP_OK(hipMalloc((void **)&x.k_cache_table, n_cache * sizeof(half)));
+        HIP_OK(hipMalloc((void **)&x.v_cache_table, n_cache * sizeof(half)));
+        HIP_OK(hipMalloc((void **)&x.seq_len, B * sizeof(int)));
+        HIP_OK(hipMemcpy(x.seq_len, lens.data(), B * sizeof(int), hipMemcpyHostToDevice));
+        const half val = __float2half(i == 0 ? 1.0f : 2.0f);
+        init_half_array((half *)x.qkv, val, (int)n_qkv, 0, 0);
+        init_half_array((half *)x.k_cache_table, __float2half(1.0f), (int)n_cache, 0, 0);
+        init_half_array((half *)x.v_cache_table, val, (int)n_cache, 0, 0);
+        init_half_array((half *)x.o, __float2half(0.0f), (int)n_o, 0, 0);
+        HIP_OK(hipStreamCreate(&st[i]));
+    }
+    HIP_OK(hipDeviceSynchronize());
+    for (int it = 0; it < iters; ++it)
+        for (int i = 0; i < 2; ++i) run_flash_decoder<half>(in[i], prm, st[i]);
+    HIP_OK(hipDeviceSynchronize());
+    int bad = 0;
+    for (int i = 0; i < 2; ++i) {
+        std::vector<half> o(n_o);
+        HIP_OK(hipMemcpy(o.data(), in[i].o, n_o * sizeof(half), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < n_o; ++j)
+            if (std::fabs(__half2float(o[j]) - (i == 0 ? 1.0f : 2.0f)) > 2e-3f) ++bad;
+        HIP_OK(hipStreamDestroy(st[i]));
+        for (void *ptr : {in[i].qkv, in[i].o, in[i].k_cache_table, in[i].v_cache_table, in[i].seq_len}) HIP_OK(hipFree(ptr));
+    }
+    printf("two streams, 4 splits, %d interleaved calls each: %s\n", iters, bad ? "WRONG (streams share scratch?)" : "ok");
+    return bad ? 1 : 0;
+}
+
 int main() {
     const int B = 2, H = 32, D = 128, L = 4, layer = 0, splits = 4;
     const int max_seq_len[6] = {512, 1024, 2048, 4096, 8192, 8192};
@@ -108,6 +161,7 @@ int main() {
     for (int i = 0; i < 6; ++i)
         rc |= run_case(B, H, D, max_seq_len[i], seq_len[i], L, layer, splits, seq_len[i] >= max_seq_len[i]);
     rc |= run_case(B, H, D, 8192, 8191, L, layer, 0, false);       // library-chosen split count
+    rc |= run_two_streams();
     printf(rc ? "FAILED\n" : "all cases ok\n");
     return rc;
 }

@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define SFA_ABI_VERSION 2
+/* Bumped whenever a struct below changes layout or an entry point changes meaning:
+ *   2  kv_layout, fast_scale
+ *   3  page_size / block_table / block_table_stride / num_pages / num_heads_kv appended to sfa_decode_args;
+ *      a block_table entry outside the pool on the APPEND page now rejects the sequence; sfa_debug_set */
+#define SFA_ABI_VERSION 3
 
 typedef enum sfa_status {
     SFA_OK = 0,
@@ -45,7 +49,8 @@ typedef enum sfa_status {
     SFA_ERR_SEQ_LEN_RANGE = -7,  /* reported by sfa_decode_poll_status: some
                                     seq_len[b] was outside [0, memory_max_len)       */
     SFA_ERR_BLOCK_TABLE_RANGE = -8 /* reported by sfa_decode_poll_status: a block_table
-                                    entry was outside [0, num_pages); page 0 was read instead */
+                                    entry was outside [0, num_pages): nothing was stored through
+                                    it and the outputs that depended on it are NaN            */
 } sfa_status;
 
 typedef enum sfa_dtype {
@@ -91,8 +96,12 @@ const char *sfa_last_error(void);            /* thread-local, never NULL        
  * Caches are [batch, num_layer, memory_max_len, num_heads, head_dim], contiguous
  * (kv_layout = SFA_KV_BLMHD), or head-major with kv_layout = SFA_KV_BLHMD.
  * seq_len is NOT incremented (caller's job, as in the reference).
- * A sequence whose seq_len is out of range is left untouched in the caches, gets
- * NaN in o[b] and raises the sticky status word (see sfa_decode_poll_status).
+ * A sequence whose seq_len is out of range -- or, with paged caches, whose
+ * block_table entry for the page the new token goes to lies outside [0, num_pages) --
+ * is left untouched in the caches, gets NaN in o[b] and raises the sticky status word
+ * (see sfa_decode_poll_status).  A bad entry on a page that is only READ is not
+ * dereferenced either (page 0 is read in its place), raises the same status and turns the
+ * outputs of that sequence's affected heads into NaN.
  */
 typedef struct sfa_decode_args {
     void *qkv;                      /* [batch, 3, num_heads, head_dim]                */
@@ -138,10 +147,12 @@ typedef struct sfa_decode_args {
 
 /* Bytes of scratch sfa_decode needs for this shape (num_splits <= 0: the library's choice
  * for this shape, which is what sfa_decode will then use). Never 0: the first 256 bytes hold
- * the status word. */
+ * the status word.  Grouped queries (num_heads_kv != num_heads): the library sizes its split
+ * count by the KV-head count (one workgroup serves a whole group), so ask
+ * sfa_decode_auto_splits(batch_size, num_heads_kv, ...) and pass that count here with num_heads. */
 size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim,
                                   int memory_max_len, int num_splits);
-/* The split count the library picks for num_splits <= 0. */
+/* The split count the library picks for num_splits <= 0; num_heads = the KV-head count. */
 int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len);
 /* Zero the sticky status word (async). Call once after allocating a workspace. */
 int sfa_decode_reset_status(void *workspace, void *stream);
@@ -189,6 +200,13 @@ typedef struct sfa_prefill_args {
 } sfa_prefill_args;
 
 int sfa_prefill_fwd(const sfa_prefill_args *args, void *stream);
+
+/* ---- test / A-B hooks: NOT part of the drop-in surface ------------------------------ */
+/* The launch paths read no environment variable; the test-suite and tools/ select kernel
+ * variants through this call.  knob: "prefill_impl" (-1 auto; kernel generation, see
+ * csrc/prefill_dispatch.hip), "prefill_pairs" (1/2), "decode_nt" (0/1), "decode_gqa_mfma" (0/1),
+ * "bm128_one_wg" (0/1), "w4_ring".  value -1 = the library's own choice.  Process-wide. */
+int sfa_debug_set(const char *knob, int value);
 
 /* ---- small helpers the reference's C++ harness uses ----------------------------- */
 /* cos/sin LUT, [max_seq_len, rot_dim/2] each, entry (pos, j) = cos/sin(pos * 10000^(-2j/rot_dim)). */

@@ -5,7 +5,7 @@ reference's fused decode attention (pure-PyTorch ground truth at
 /root/reference/examples/python/testFlashDecoder.py:61-94) and of plain
 scaled-dot-product attention (the prefill path, which has no reference code).
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_cabi_cpu.py::test_product_never_imports_oracle):
   * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
     import anything from here;
   * the product (starflashattention_amd/, star_flash_attn) never does, and has

@@ -15,7 +15,8 @@
 //   * biases are honoured (the reference accepts and drops them); an empty tensor means "none";
 //   * the call is asynchronous on the current stream -- no device-wide sync, no per-call malloc;
 //   * num_splits is chosen by the library (the reference hard-codes 4);
-//   * additive entry points: mha_fwd (prefill forward), compute_rotary_table, check_errors.
+//   * additive entry points: mha_fwd (prefill forward), compute_rotary_table, check_errors,
+//     release_workspaces.
 #include <ATen/hip/HIPContext.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm tensors say "cuda"
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -60,10 +61,24 @@ at::Tensor &workspace(const at::Device &dev, hipStream_t stream, size_t need) {
     at::Tensor &ws = g_workspaces[{dev.index(), (void *)stream}];
     if (!ws.defined() || (size_t)ws.numel() < need) {
         const int64_t bytes = std::max<int64_t>((int64_t)need, 1 << 20);
-        ws = at::empty({bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
-        check_status(sfa_decode_reset_status(ws.data_ptr(), stream), "workspace");
+        at::Tensor grown = at::empty({bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+        if (ws.defined()) {
+            // carry the sticky status block over, in stream order (no sync): a raised flag survives growth
+            TORCH_CHECK(hipMemcpyAsync(grown.data_ptr(), ws.data_ptr(), 256, hipMemcpyDeviceToDevice, stream) == hipSuccess,
+                        "star_flash_attn: workspace: hipMemcpyAsync failed");
+        } else {
+            check_status(sfa_decode_reset_status(grown.data_ptr(), stream), "workspace");
+        }
+        ws = grown;     // the old block goes back to the caching allocator, which keeps it stream-ordered
     }
     return ws;
+}
+
+// Drop every cached workspace (they are otherwise kept for the life of the process, one per
+// (device, stream) that ever decoded).  Pending sticky flags are lost: call check_errors() first.
+void release_workspaces() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_workspaces.clear();
 }
 
 const void *opt_ptr(const at::Tensor &t) { return (t.defined() && t.numel() > 0) ? t.data_ptr() : nullptr; }
@@ -237,6 +252,8 @@ PYBIND11_MODULE(star_flash_attn, m) {
           py::arg("max_input_length"), py::arg("num_layer"), py::arg("idx_layer"));
     m.def("check_errors", &check_errors,
           "Synchronise the current stream and raise if a decode call saw an out-of-range seq_len");
+    m.def("release_workspaces", &release_workspaces,
+          "Free the cached decode scratch of every (device, stream); call check_errors() first if flags matter");
     m.def("mha_fwd", &mha_fwd, "Attention forward (prefill): returns [out] or [out, lse]",
           py::arg("q"), py::arg("k"), py::arg("v"), py::arg("out") = py::none(), py::arg("causal") = false,
           py::arg("softmax_scale") = 0.0, py::arg("return_lse") = false, py::arg("fast_scale") = false);

@@ -7,7 +7,7 @@
 
 // One decode step (fused RoPE + KV append + split-KV attention).  T = half or hip_bfloat16-sized
 // 16-bit type; explicit instantiations exist for __half and __hip_bfloat16.
-// Asynchronous on `stream`.  Scratch comes from a per-device workspace owned by the library (grown
+// Asynchronous on `stream`.  Scratch comes from a workspace per (device, stream) owned by the library (grown
 // on first use -- do that outside graph capture).  Throws std::runtime_error on bad arguments.
 template <typename T>
 void run_flash_decoder(Flash_decoder_input &input, Flash_decoder_params &params, hipStream_t stream);

@@ -6,10 +6,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libStarFlashAttention.so")
+# SFA_LIB_PATH: load another build of the same ABI instead (the A/B library with the earlier kernel
+# generations, libStarFlashAttention_ab.so -- pytest -m variants, tools/prefill_ab.py)
+LIB_PATH = os.environ.get("SFA_LIB_PATH") or os.path.join(_HERE, "lib", "libStarFlashAttention.so")
 
 SFA_OK = 0
-ABI_VERSION = 2          # SFA_ABI_VERSION in include/star_flash_attn.h
+ABI_VERSION = 3          # SFA_ABI_VERSION in include/star_flash_attn.h
 SFA_ERR_SEQ_LEN_RANGE = -7
 SFA_ERR_BLOCK_TABLE_RANGE = -8
 DTYPE_FP16, DTYPE_BF16 = 0, 1
@@ -19,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "sfa_abi_version", "sfa_status_string", "sfa_last_error",
     "sfa_decode_workspace_bytes", "sfa_decode_auto_splits", "sfa_decode_reset_status",
     "sfa_decode_poll_status", "sfa_decode", "sfa_prefill_fwd",
-    "sfa_compute_rotary_table", "sfa_fill_16bit",
+    "sfa_compute_rotary_table", "sfa_fill_16bit", "sfa_debug_set",
 ]
 
 
@@ -99,10 +101,17 @@ def load():
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sfa_fill_16bit.restype = ctypes.c_int
     lib.sfa_fill_16bit.argtypes = [ctypes.c_void_p, ctypes.c_uint16, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sfa_debug_set.restype = ctypes.c_int
+    lib.sfa_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
     if lib.sfa_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.sfa_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+def debug_set(knob, value):
+    """Test / A-B hook (sfa_debug_set): pick a kernel variant; -1 = the library's own choice."""
+    check(load().sfa_debug_set(knob.encode(), int(value)))
 
 
 def check(status):

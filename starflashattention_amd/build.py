@@ -25,8 +25,14 @@ ARCH = "gfx950"
 
 EXTRA_FLAGS = {}      # per-source extra hipcc flags (none needed at present)
 
-KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_kernel.hip", "prefill_kernel16.hip", "prefill_kernel_bm128.hip", "prefill_baseline.hip", "prefill_dispatch.hip",
+KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_w4_kernel.hip",
+                  "prefill_kernel.hip", "prefill_kernel_bm128.hip", "prefill_dispatch.hip",
                   "aux_kernels.hip", "c_api.hip", "cxx_surface.hip"]
+# Earlier kernel generations kept for A/B runs (tools/prefill_ab.py, pytest -m variants).  They are never an
+# auto choice of launch_prefill, so the shipping library does not carry them: build_lib(variants=True)
+# compiles them (and -DSFA_WITH_VARIANTS) into a second library, libStarFlashAttention_ab.so.
+VARIANT_SOURCES = ["prefill_kernel16.hip", "prefill_baseline.hip"]
+AB_LIB_NAME = "libStarFlashAttention_ab.so"
 
 
 def hipcc():
@@ -59,14 +65,17 @@ def _headers():
     return [h for h in hs if os.path.exists(h)]
 
 
-def build_lib(force=False, verbose=False, extra_flags=()):
-    """hipcc -> starflashattention_amd/lib/libStarFlashAttention.so; returns its path."""
+def build_lib(force=False, verbose=False, extra_flags=(), variants=False):
+    """hipcc -> starflashattention_amd/lib/libStarFlashAttention.so; returns its path.
+    variants=True builds the A/B library (earlier kernel generations included) next to it instead."""
+    objdir = OBJDIR + ("_ab" if variants else "")
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
-    out = os.path.join(LIBDIR, LIB_NAME)
-    srcs = [os.path.join(CSRC, s) for s in KERNEL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(LIBDIR, AB_LIB_NAME if variants else LIB_NAME)
+    names = KERNEL_SOURCES + (VARIANT_SOURCES if variants else [])
+    srcs = [os.path.join(CSRC, s) for s in names]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + ROOT,
-             "-Wall", "-Wno-unused-function"] + list(extra_flags)
+             "-Wall", "-Wno-unused-function"] + (["-DSFA_WITH_VARIANTS=1"] if variants else []) + list(extra_flags)
     stamp = _stamp(srcs + _headers(), " ".join(flags) + repr(sorted(EXTRA_FLAGS.items())))
     stamp_file = out + ".stamp"
     if (not force and os.path.exists(out) and os.path.exists(stamp_file)
@@ -75,7 +84,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     cc = hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         log = _run([cc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
         if verbose and log.strip():
             print(log)
@@ -133,7 +142,8 @@ def build_examples(force=False, verbose=False):
     if (not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(lib))):
         return out
     log = _run([hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-I" + ROOT, src, "-L" + LIBDIR,
-                "-lStarFlashAttention", "-Wl,-rpath,$ORIGIN/../starflashattention_amd/lib", "-o", out])
+                "-lStarFlashAttention", "-L/opt/rocm/lib", "-lroctx64",
+                "-Wl,-rpath,$ORIGIN/../starflashattention_amd/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     if verbose and log.strip():
         print(log)
     return out
@@ -147,6 +157,8 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     only_lib = "--lib-only" in sys.argv
     print(build_lib(force, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_lib(force, verbose=True, variants=True))
     if not only_lib:
         print(build_pybind(force, verbose=True))
         print(build_examples(force, verbose=True))

@@ -38,7 +38,32 @@ fill16_kernel(uint16_t *arr, uint16_t bits, size_t n) {
     }
 }
 
+// Prefill with no keys at all: every row is empty -> O = 0, lse = -inf (include/star_flash_attn.h).
+// One thread per 16 bytes of O; rows are addressed through the caller's strides.
+__global__ void __launch_bounds__(256)
+prefill_no_keys_kernel(const PrefillKernelParams p, int head_dim) {
+    const int cpr = head_dim / 8;
+    const long long n = (long long)p.B * p.Hq * p.Sq * cpr;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = (int)(i % cpr);
+    const long long row = i / cpr;
+    const int s = (int)(row % p.Sq);
+    const long long bh = row / p.Sq;
+    const int h = (int)(bh % p.Hq);
+    const long long b = bh / p.Hq;
+    *reinterpret_cast<uint4 *>(p.o + b * p.os[0] + h * p.os[1] + s * p.os[2] + 8 * ch) = make_uint4(0, 0, 0, 0);
+    if (p.lse && ch == 0) p.lse[row] = -__builtin_huge_valf();
+}
+
 }  // namespace
+
+int launch_prefill_no_keys(const PrefillKernelParams &p, int head_dim, hipStream_t stream) {
+    const long long n = (long long)p.B * p.Hq * p.Sq * (head_dim / 8);
+    if (n == 0) return SFA_OK;
+    hipLaunchKernelGGL(prefill_no_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, head_dim);
+    return check_launch("prefill_no_keys_kernel");
+}
 
 int launch_rotary_table(void *cos_t, void *sin_t, int max_seq_len, int rot_dim, int dtype, hipStream_t stream) {
     const int half = rot_dim / 2;

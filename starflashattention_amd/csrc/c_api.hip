@@ -13,6 +13,8 @@ namespace sfa {
 
 static thread_local char g_err[512] = "";
 
+DebugKnobs g_knobs;
+
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -79,6 +81,20 @@ const char *sfa_status_string(int status) {
 }
 
 const char *sfa_last_error(void) { return g_err; }
+
+int sfa_debug_set(const char *knob, int value) {
+    if (!knob) return fail(SFA_ERR_NULL_POINTER, "sfa_debug_set: knob is NULL");
+    std::atomic<int> *k = nullptr;
+    if (!strcmp(knob, "prefill_impl")) k = &g_knobs.prefill_impl;
+    else if (!strcmp(knob, "prefill_pairs")) k = &g_knobs.prefill_pairs;
+    else if (!strcmp(knob, "decode_nt")) k = &g_knobs.decode_nt;
+    else if (!strcmp(knob, "decode_gqa_mfma")) k = &g_knobs.decode_gqa_mfma;
+    else if (!strcmp(knob, "bm128_one_wg")) k = &g_knobs.bm128_one_wg;
+    else if (!strcmp(knob, "w4_ring")) k = &g_knobs.w4_ring;
+    else return fail(SFA_ERR_BAD_SHAPE, "sfa_debug_set: unknown knob '%s'", knob);
+    k->store(value, std::memory_order_relaxed);
+    return SFA_OK;
+}
 
 int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len) {
     if (batch_size <= 0 || num_heads <= 0 || memory_max_len <= 0) return 1;
@@ -174,9 +190,10 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     if (align_or & 15) return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: tensors must be 16-byte aligned");
     if (a->batch_size == 0) return SFA_OK;
 
+    // grouped queries launch one workgroup per KV head: the split count follows the kv-head count
     const int S = a->num_splits > 0
                       ? a->num_splits
-                      : auto_splits(a->batch_size, a->num_heads, a->head_dim, a->memory_max_len);
+                      : auto_splits(a->batch_size, hkv, a->head_dim, a->memory_max_len);
     const size_t need = sfa_decode_workspace_bytes(a->batch_size, a->num_heads, a->head_dim,
                                                    a->memory_max_len, S);
     if (!a->workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode: workspace is NULL (need %zu bytes)", need);
@@ -255,11 +272,6 @@ int sfa_prefill_fwd(const sfa_prefill_args *a, void *stream) {
     if ((long long)a->batch * a->heads_q > (1ll << 24))
         return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: batch*heads_q too large");
     if (a->batch == 0 || a->seqlen_q == 0) return SFA_OK;
-    if (a->seqlen_k == 0) {
-        // no keys: every row is empty -> zeros (the kernel handles nt == 0, but it clamps key
-        // rows to Sk-1 when staging, so give it nothing to read)
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: seqlen_k must be > 0");
-    }
 
     PrefillKernelParams p;
     memset(&p, 0, sizeof(p));
@@ -282,6 +294,8 @@ int sfa_prefill_fwd(const sfa_prefill_args *a, void *stream) {
     }
     const float scale = a->softmax_scale > 0.f ? a->softmax_scale : 1.0f / std::sqrt((float)a->head_dim);
     p.scale_log2 = scale * 1.4426950408889634f;
+    if (a->seqlen_k == 0)       // no keys: every row is empty -> zeros, lse = -inf (the header's promise)
+        return launch_prefill_no_keys(p, a->head_dim, (hipStream_t)stream);
     p.nq_tiles = (a->seqlen_q + 255) / 256;
     p.bh_per_xcd = (a->batch * a->heads_q + 7) / 8;
     if ((long long)8 * p.bh_per_xcd * p.nq_tiles > 0x7fffffffll)

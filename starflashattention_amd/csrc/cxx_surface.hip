@@ -1,13 +1,20 @@
 // The C++ template surface declared in src/flash_attn.h, implemented over the C ABI.
 // (Reference: run_flash_decoder<T> flash_attn.cu:937-1018 allocates, copies and frees on every call
-// and synchronises the device; here scratch is a per-device grow-only workspace and nothing syncs.)
+// and synchronises the device; here scratch is a grow-only workspace per (device, stream) -- the split
+// partials of two streams never share memory -- and nothing syncs.)
+// SFA_ROCTX=1 in the environment AT LOAD TIME wraps every run_flash_decoder call in a roctx range
+// (the reference brackets its timed loop with NVTX, examples/cpp/testFlashDecoder.cc:99-106); the
+// roctx library is opened with dlopen, so nothing links against it.
+#include <dlfcn.h>
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
-#include <unordered_map>
+#include <utility>
 
 #include <src/flash_attn.h>
 
@@ -17,7 +24,28 @@ namespace {
 
 struct Workspace { void *ptr = nullptr; size_t bytes = 0; };
 std::mutex g_mu;
-std::unordered_map<int, Workspace> g_ws;      // per device
+std::map<std::pair<int, hipStream_t>, Workspace> g_ws;      // per (device, stream), as the pybind layer keys its own
+
+// roctx ranges, decided once when the library is loaded
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = std::getenv("SFA_ROCTX");
+        if (!e || !std::atoi(e)) return;
+        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx g_roctx;
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { if (g_roctx.push) g_roctx.push(name); }
+    ~RoctxRange() { if (g_roctx.push) g_roctx.pop(); }
+};
 
 [[noreturn]] void raise(const char *what) {
     throw std::runtime_error(std::string(what) + ": " + sfa_last_error());
@@ -27,10 +55,19 @@ Workspace &workspace_for(size_t need, hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_mu);
-    Workspace &w = g_ws[dev];
+    Workspace &w = g_ws[{dev, stream}];
     if (w.bytes < need) {
+        // growing allocates and (when a block exists) synchronises: not legal inside a stream capture --
+        // make the first call of a shape outside the capture (src/flash_attn.h)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            throw std::runtime_error("run_flash_decoder: the workspace must grow, which cannot happen during stream "
+                                     "capture; call once with this shape before capturing");
+        int32_t sticky = 0;
         if (w.ptr) {
-            (void)hipStreamSynchronize(stream);       // earlier calls may still read the old block
+            // earlier calls on this stream may still use the old block; carry its sticky status word over
+            (void)hipMemcpyAsync(&sticky, w.ptr, sizeof(sticky), hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
             (void)hipFree(w.ptr);
         }
         size_t bytes = need < (1u << 20) ? (1u << 20) : need;
@@ -40,6 +77,8 @@ Workspace &workspace_for(size_t need, hipStream_t stream) {
         }
         w.bytes = bytes;
         if (sfa_decode_reset_status(w.ptr, stream) != SFA_OK) raise("run_flash_decoder");
+        if (sticky) (void)hipMemcpyAsync(w.ptr, &sticky, sizeof(sticky), hipMemcpyHostToDevice, stream),
+                    (void)hipStreamSynchronize(stream);
     }
     return w;
 }
@@ -53,6 +92,7 @@ template <typename T> constexpr int dtype_of() {
 
 template <typename T>
 void run_flash_decoder(Flash_decoder_input &in, Flash_decoder_params &params, hipStream_t stream) {
+    const RoctxRange range("run_flash_decoder");
     sfa_decode_args a = {};             // zero: the reference layout, no paging, num_heads_kv = num_heads
     a.qkv = in.qkv;
     a.q_bias = in.q_bias;
@@ -101,17 +141,20 @@ void init_half_array(half *array, half value, int n, int /*numBlocks*/, int /*bl
 void check_flash_decoder_status() {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    Workspace w;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        w = g_ws[dev];
-    }
-    if (!w.ptr) return;
     if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
-    const int st = sfa_decode_poll_status(w.ptr, nullptr);
-    if (st != SFA_OK) {
-        (void)sfa_decode_reset_status(w.ptr, nullptr);
-        raise("run_flash_decoder");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int worst = SFA_OK;
+    for (auto &kv : g_ws) {                     // every stream's workspace of this device
+        if (kv.first.first != dev || !kv.second.ptr) continue;
+        const int st = sfa_decode_poll_status(kv.second.ptr, nullptr);
+        if (st != SFA_OK) {
+            (void)sfa_decode_reset_status(kv.second.ptr, nullptr);
+            worst = st;
+        }
+    }
+    if (worst != SFA_OK) {
+        throw std::runtime_error("run_flash_decoder: a seq_len[b] was outside [0, memory_max_len) or a block_table "
+                                 "entry outside the pool; those outputs are NaN and their cache rows were not written");
     }
 }
 

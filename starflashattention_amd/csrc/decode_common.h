@@ -44,6 +44,20 @@ __device__ __forceinline__ uint4 ld16(const uint16_t *p) {
     return *reinterpret_cast<const uint4 *>(p);
 }
 
+// Which sticky status bit a sequence raises before anything is touched: 1 = seq_len[b] outside
+// [0, memory_max_len); 2 = (paged caches) the block_table entry of the page the new token would be
+// appended to lies outside the pool -- storing through a substituted page would corrupt another
+// sequence.  0 = fine.  Wave-uniform; every workgroup of batch b computes the same value.
+template <bool PAGED>
+__device__ __forceinline__ int reject_code(const DecodeKernelParams &p, int b, int pos) {
+    if (pos < 0 || pos >= p.M) return 1;
+    if (PAGED) {
+        const int pg = p.block_table[(long long)b * p.table_stride + (pos >> p.page_shift)];
+        if ((unsigned)pg >= (unsigned)p.num_pages) return 2;
+    }
+    return 0;
+}
+
 // Running softmax state of one lane group: max (log2 units), sum, and this lane's 8 output dims.
 struct Stream {
     float m, l, acc[8];

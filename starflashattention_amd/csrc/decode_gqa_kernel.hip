@@ -38,11 +38,12 @@ decode_gqa_kernel(const DecodeKernelParams p) {
     const int Hq = p.H, Hkv = p.Hkv;
 
     const int pos = p.seq_len[b];
-    if (pos < 0 || pos >= p.M) {        // same contract as decode_kernel: poison, flag, touch nothing
+    const int reject = reject_code<PAGED>(p, b, pos);      // same contract as decode_kernel: poison, flag, touch nothing
+    if (reject) {
         if (split == 0) {
             for (int i = tid; i < G * D; i += W * 64)
                 p.o[((long long)b * Hq + (long long)hk * G) * D + i] = Tr::id == 0 ? 0x7e00 : 0x7fc0;
-            if (tid == 0 && hk == 0) atomicOr(p.status, 1);
+            if (tid == 0 && hk == 0) atomicOr(p.status, reject);
         }
         return;
     }
@@ -125,10 +126,12 @@ decode_gqa_kernel(const DecodeKernelParams p) {
     const uint16_t *vb = p.v_cache + head_base;
     const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;
     const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    int bad_page = 0;
     auto page_of = [&](int idx) -> int {
         int pg = tbl[idx];
         if ((unsigned)pg >= (unsigned)p.num_pages) {
             if (tid == 0) atomicOr(p.status, 2);
+            bad_page = 1;       // a read page outside the pool: page 0 is read instead, the output becomes NaN
             pg = 0;
         }
         return pg;
@@ -223,6 +226,11 @@ decode_gqa_kernel(const DecodeKernelParams p) {
         }
     }
 
+    if (PAGED && bad_page) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) st[g].l = __builtin_nanf("");
+    }
+
     // ---- merge lane groups (same dims, different rows), then the waves through LDS ----
     __shared__ float red[W][G][D + 2];
 #pragma unroll
@@ -273,7 +281,7 @@ template <class Tr, int D, int G>
 int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
     bool nt = 4ll * p.B * p.L * p.M * p.Hkv * D > (256ll << 20);       // see decode_kernel.hip
-    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+    if (const int k = g_knobs.decode_nt.load(std::memory_order_relaxed); k >= 0) nt = k != 0;      // tests, A/B
     if (p.block_table) {
         if (nt) hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, true, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((decode_gqa_kernel<Tr, D, G, false, true>), grid, block, 0, stream, p);
@@ -299,10 +307,10 @@ int launch_t(const DecodeKernelParams &p, hipStream_t stream) {
 // the attention kernel only; launch_decode (decode_kernel.hip) adds the split combine
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
     // 8 query heads per kv head make this kernel VALU-bound (4.1 TB/s): the matrix-core form takes over
-    // (head_dim 128; SFA_DECODE_GQA_MFMA=0 keeps the VALU kernel for A/B)
+    // (head_dim 128; sfa_debug_set("decode_gqa_mfma", 0) keeps the VALU kernel for A/B)
     if (head_dim == 128 && (p.H == 16 * p.Hkv || p.H == 8 * p.Hkv || p.H == 4 * p.Hkv) && (dtype == SFA_DTYPE_FP16 || dtype == SFA_DTYPE_BF16)) {
-        const char *e = std::getenv("SFA_DECODE_GQA_MFMA");
-        if (!e || std::atoi(e) != 0 || p.H == 16 * p.Hkv) return launch_decode_gqa_mfma(p, dtype, stream);
+        if (g_knobs.decode_gqa_mfma.load(std::memory_order_relaxed) != 0 || p.H == 16 * p.Hkv)
+            return launch_decode_gqa_mfma(p, dtype, stream);
     }
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_t<Fp16, 128>(p, stream);

@@ -54,11 +54,12 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     const int Hq = p.H, Hkv = p.Hkv;
 
     const int pos = p.seq_len[b];
-    if (pos < 0 || pos >= p.M) {                // same contract as decode_kernel: poison, flag, touch nothing
+    const int reject = reject_code<PAGED>(p, b, pos);      // same contract as decode_kernel: poison, flag, touch nothing
+    if (reject) {
         if (split == 0) {
             for (int i = tid; i < G * D; i += W * 64)
                 p.o[((long long)b * Hq + (long long)hk * G) * D + i] = Tr::id == 0 ? 0x7e00 : 0x7fc0;
-            if (tid == 0 && hk == 0) atomicOr(p.status, 1);
+            if (tid == 0 && hk == 0) atomicOr(p.status, reject);
         }
         return;
     }
@@ -164,10 +165,12 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
                                       : ((long long)b * p.L + p.layer) * p.M * Hkv * D + hk * p.kv_head_stride;
     const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;
     const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    int bad_page = 0;
     auto page_of = [&](int idx) -> long long {
         int pg = tbl[idx];
         if ((unsigned)pg >= (unsigned)p.num_pages) {
             if (tid == 0) atomicOr(p.status, 2);
+            bad_page = 1;       // a read page outside the pool: page 0 is read instead, the output becomes NaN
             pg = 0;
         }
         return pg * p.page_stride;
@@ -332,6 +335,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     }
 
     // ---- merge the workgroup's waves through LDS (after every wave is done with its V tiles) ----
+    if (PAGED && bad_page) l = __builtin_nanf("");
     const float ltot = quad_sum(l);             // the four lane groups hold disjoint keys of query c
     __syncthreads();
     float *const red = reinterpret_cast<float *>(smem);                 // [W][G][D + 2]
@@ -376,12 +380,10 @@ int launch_k(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
     constexpr int lds = kDecodeWaves * kTile * ((2 * 128 + 32) + (2 * 128 + 16));       // 71,680 B
     static_assert(lds >= kDecodeWaves * G * (128 + 2) * 4, "merge area fits");
-    static bool attr_set = false;       // idempotent; a race only repeats the call
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    if (const int rc = attr.ensure(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>), lds,
+                                   "decode_gqa_mfma_kernel"))
+        return rc;
     hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>), grid, block, lds, stream, p);
     return check_launch("decode_gqa_mfma_kernel");
 }
@@ -389,7 +391,7 @@ int launch_k(const DecodeKernelParams &p, hipStream_t stream) {
 template <class Tr, int G>
 int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
     bool nt = 4ll * p.B * p.L * p.M * p.Hkv * 128 > (256ll << 20);      // see decode_kernel.hip
-    if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+    if (const int k = g_knobs.decode_nt.load(std::memory_order_relaxed); k >= 0) nt = k != 0;      // tests, A/B
     // Reference layout: a K row of this head is a 256-B segment H*D*2 bytes from the next, and fetching it
     // as 64-B operand pieces costs 8 % (5.96 vs 6.44 TB/s): load row-major, re-lay out through LDS.
     // Head-major caches are contiguous, the operand-layout loads go straight to registers (6.7 TB/s).

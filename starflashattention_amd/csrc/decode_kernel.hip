@@ -44,11 +44,13 @@ decode_kernel(const DecodeKernelParams p) {
     const int S = p.num_splits;
 
     const int pos = p.seq_len[b];
-    if (pos < 0 || pos >= p.M) {
-        // out-of-range sequence: touch no cache row, poison the output, raise the sticky flag
+    // out-of-range sequence, or (paged) an append page outside the pool: touch no cache row, poison the
+    // output, raise the sticky flag.  Every workgroup of batch b takes the same decision.
+    const int reject = reject_code<PAGED>(p, b, pos);
+    if (reject) {
         if (split == 0) {
             if (tid < D) p.o[((long long)b * p.H + h) * D + tid] = Tr::id == 0 ? 0x7e00 : 0x7fc0;
-            if (tid == 0 && h == 0) atomicOr(p.status, 1);
+            if (tid == 0 && h == 0) atomicOr(p.status, reject);
         }
         return;
     }
@@ -124,10 +126,15 @@ decode_kernel(const DecodeKernelParams p) {
     const uint16_t *vb = p.v_cache + head_base;
     const int32_t *tbl = PAGED ? p.block_table + (long long)b * p.table_stride : nullptr;   // uniform
     const int pmask = PAGED ? (1 << p.page_shift) - 1 : 0;
+    // A READ page outside the pool is not dereferenced: page 0 is read in its place, the sticky flag is
+    // raised and the workgroup's row sum becomes NaN, so o[b, h] comes out NaN instead of plausible.
+    // (The append page was checked above: nothing is ever stored through a substituted page.)
+    int bad_page = 0;
     auto page_of = [&](int idx) -> int {        // scalar: table entry, clamped into the pool
         int pg = tbl[idx];
         if ((unsigned)pg >= (unsigned)p.num_pages) {
             if (tid == 0) atomicOr(p.status, 2);        // sticky: a block_table entry outside the pool
+            bad_page = 1;
             pg = 0;
         }
         return pg;
@@ -222,6 +229,8 @@ decode_kernel(const DecodeKernelParams p) {
         }
     }
 
+    if (PAGED && bad_page) st.l = __builtin_nanf("");
+
     // ---- merge lane groups (same dims, different rows) ----
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -278,7 +287,7 @@ decode_combine_kernel(const DecodeKernelParams p) {
     if (bh >= (long long)p.B * p.H) return;
     const int b = (int)(bh / p.H);
     const int pos = p.seq_len[b];
-    if (pos < 0 || pos >= p.M) return;         // decode_kernel already poisoned o[b]
+    if (p.block_table ? reject_code<true>(p, b, pos) : reject_code<false>(p, b, pos)) return;   // o[b] is already poisoned
     const int S = p.num_splits;
     Stream tot;
     tot.init();
@@ -308,9 +317,9 @@ int launch_decode_t(const DecodeKernelParams &p, int dtype, hipStream_t stream) 
         // The cache rows are read exactly once per call.  When the two caches together do not fit the
         // 256 MB Infinity Cache nothing of them survives until the next token's call either, so they are
         // loaded non-temporally (config 4: 6.30 -> 6.51 TB/s); a small cache keeps the default policy
-        // and is re-read from the Infinity Cache / L2.  SFA_DECODE_NT=0/1 overrides (tests, A/B).
+        // and is re-read from the Infinity Cache / L2.  sfa_debug_set("decode_nt", 0/1) overrides (tests, A/B).
         bool nt = 4ll * p.B * p.L * p.M * p.H * D > (256ll << 20);
-        if (const char *e = std::getenv("SFA_DECODE_NT")) nt = std::atoi(e) != 0;
+        if (const int k = g_knobs.decode_nt.load(std::memory_order_relaxed); k >= 0) nt = k != 0;      // tests, A/B
         if (p.block_table) {
             // a step of at most 16 rows touches at most two pages (page_size >= 16)
             constexpr int UP = (16 / (64 / (D / 8))) < 4 ? (16 / (64 / (D / 8))) : 4;

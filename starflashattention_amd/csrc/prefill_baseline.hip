@@ -240,14 +240,12 @@ template <class Tr, int D>
 int launch_prefill_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     const size_t lds = 4 * (size_t)kBN * D * 2;
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
-    static bool attr_set = false;       // idempotent; a race only repeats the call
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static DynLdsAttr attr_c, attr_f;
+    if (const int rc = causal ? attr_c.ensure(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, true>),
+                                              (int)lds, "prefill_kernel_baseline")
+                              : attr_f.ensure(reinterpret_cast<const void *>(&prefill_kernel_baseline<Tr, D, false>),
+                                              (int)lds, "prefill_kernel_baseline"))
+        return rc;
     if (causal) {
         hipLaunchKernelGGL((prefill_kernel_baseline<Tr, D, true>), grid, block, lds, stream, p);
     } else {

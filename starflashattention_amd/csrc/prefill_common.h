@@ -51,5 +51,10 @@ int launch_prefill_bm128(const PrefillKernelParams &p, int dtype, int head_dim, 
 int launch_prefill_x16(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
                        int force = 0);
 int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+// the 4-wave persistent kernel (prefill_w4_kernel.hip); force: 0 = flavour by policy, 1 = prescaled, 2 = exact
+int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
+                      int force = 0);
+// q-tiles (256 rows) a problem must have before the auto rule picks the persistent kernel: two per CU
+constexpr long long kW4MinTiles = 512;
 
 }  // namespace sfa

@@ -427,21 +427,17 @@ int launch_t(const PrefillKernelParams &p_in, bool causal, hipStream_t stream) {
     // One pair per workgroup.  Two pairs (half the dispatches and staging prologues again) are
     // supported and tested, but measured 920 vs 941 TFLOPS on the headline shape, so they stay opt-in.
     p.pairs_per_wg = 1;
-    if (const char *e = std::getenv("SFA_PREFILL_PAIRS")) {     // tests / A-B runs: force 1 or 2
-        const int v = std::atoi(e);
-        if (v == 1 || v == 2) p.pairs_per_wg = v;
-    }
+    if (const int v = g_knobs.prefill_pairs.load(std::memory_order_relaxed); v == 1 || v == 2)
+        p.pairs_per_wg = v;                     // tests / A-B runs
     p.nq_tiles = (npairs + p.pairs_per_wg - 1) / p.pairs_per_wg;      // workgroup slots per head
     const size_t lds = Lds<D>::TOTAL;          // K[3] + V[3], padded rows
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads);
-    static bool attr_set = false;       // idempotent; a race only repeats the call
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true, PF, ORD, DIAG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false, PF, ORD, DIAG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static DynLdsAttr attr_c, attr_f;
+    if (const int rc = causal ? attr_c.ensure(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, true, PF, ORD, DIAG>),
+                                              (int)lds, "prefill_kernel")
+                              : attr_f.ensure(reinterpret_cast<const void *>(&prefill_kernel<Tr, D, false, PF, ORD, DIAG>),
+                                              (int)lds, "prefill_kernel"))
+        return rc;
     if (causal) {
         hipLaunchKernelGGL((prefill_kernel<Tr, D, true, PF, ORD, DIAG>), grid, block, lds, stream, p);
     } else {

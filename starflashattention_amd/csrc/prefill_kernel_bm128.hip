@@ -305,12 +305,12 @@ int launch_t(const PrefillKernelParams &p_in, bool causal, int force, hipStream_
     PrefillKernelParams p = p_in;
     p.nq_tiles = (p.Sq + kBM2 - 1) / kBM2;              // 128-row q-tiles
     size_t lds = Lds<D, kBN2, 3, 2>::TOTAL;
-    if (const char *e = std::getenv("SFA_BM128_ONE_WG")) {      // diagnostic: one workgroup (one wave per SIMD) per CU
-        if (std::atoi(e)) {
-            lds = 100 * 1024;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_kernel_bm128<Tr, D, true, 2, 6>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
+    if (g_knobs.bm128_one_wg.load(std::memory_order_relaxed) > 0) {     // diagnostic: one workgroup (one wave per SIMD) per CU
+        lds = 100 * 1024;
+        static DynLdsAttr attr;
+        if (const int rc = attr.ensure(reinterpret_cast<const void *>(&prefill_kernel_bm128<Tr, D, true, 2, 6>), (int)lds,
+                                       "prefill_kernel_bm128"))
+            return rc;
     }
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads2);
     // same policy as the 256-row kernel: exact scale unless the caller opted into the prescaled-Q

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <atomic>
+
 #include "../../include/star_flash_attn.h"
 
 namespace sfa {
@@ -53,9 +55,41 @@ int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStrea
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
 int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream);
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
+int launch_prefill_no_keys(const PrefillKernelParams &p, int head_dim, hipStream_t stream);
 int launch_rotary_table(void *cos_t, void *sin_t, int max_seq_len, int rot_dim, int dtype, hipStream_t stream);
 int launch_fill16(void *arr, uint16_t bits, size_t n, hipStream_t stream);
 
 int check_launch(const char *what);
+
+// Test / A-B knobs, set through sfa_debug_set() (include/star_flash_attn.h) and nothing else: the launch
+// paths read no environment variable.  -1 = the library's own choice.
+struct DebugKnobs {
+    std::atomic<int> prefill_impl{-1};      // prefill_dispatch.hip: which prefill kernel generation
+    std::atomic<int> prefill_pairs{-1};     // prefill_kernel.hip: balanced q-tile pairs per workgroup (1 or 2)
+    std::atomic<int> decode_nt{-1};         // decode kernels: 0 / 1 force default / non-temporal cache loads
+    std::atomic<int> decode_gqa_mfma{-1};   // decode_gqa_kernel.hip: 0 forces the VALU grouped-query kernel
+    std::atomic<int> bm128_one_wg{-1};      // prefill_kernel_bm128.hip: 1 = one workgroup per CU (diagnostic)
+    std::atomic<int> w4_ring{-1};           // prefill_w4_kernel.hip: diagnostic variant selector
+};
+extern DebugKnobs g_knobs;
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one of these per kernel
+// instantiation (a function-local static) remembers which devices of the process already have it.
+struct DynLdsAttr {
+    std::atomic<unsigned long long> done{0};
+    // SFA_OK, or SFA_ERR_LAUNCH with the HIP error text
+    int ensure(const void *func, int bytes, const char *what) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return fail(SFA_ERR_LAUNCH, "%s: hipGetDevice failed", what);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_relaxed) & bit) return SFA_OK;
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess)
+            return fail(SFA_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %d bytes on device %d: %s", what, bytes, dev,
+                        hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_relaxed);
+        return SFA_OK;
+    }
+};
 
 }  // namespace sfa

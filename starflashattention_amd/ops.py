@@ -54,10 +54,19 @@ def _workspace(device, nbytes):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _lib.check(lib.sfa_decode_reset_status(ctypes.c_void_p(ws.data_ptr()), _stream_ptr(device)))
-        _workspaces[key] = ws
+        grown = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is None:
+            _lib.check(lib.sfa_decode_reset_status(ctypes.c_void_p(grown.data_ptr()), _stream_ptr(device)))
+        else:
+            grown[:256].copy_(ws[:256])      # the sticky status block survives growth (stream-ordered, no sync)
+        _workspaces[key] = ws = grown
     return ws
+
+
+def release_workspaces():
+    """Drop the cached decode scratch of every (device, stream).  Pending sticky flags are lost:
+    call check_decode_status() first if they matter."""
+    _workspaces.clear()
 
 
 def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_len, o,
@@ -106,7 +115,7 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         if t is not None:
             _check_gpu_tensor(t, name, dt, (M, int(rotary_embedding_dim) // 2), dev)
     with torch.cuda.device(dev):
-        # grouped queries launch one workgroup per KV head: size the split count by those
+        # the library sizes the split count by the KV heads (one workgroup serves a whole group)
         S = int(num_splits) if num_splits and num_splits > 0 else lib.sfa_decode_auto_splits(B, Hkv, D, M)
         ws = _workspace(dev, lib.sfa_decode_workspace_bytes(B, H, D, M, S))
         a = _lib.DecodeArgs()
@@ -157,7 +166,7 @@ def check_decode_status(device=None):
 
 def flash_attn_fwd(q, k, v, causal=False, softmax_scale=None, out=None, return_lse=False, fast_scale=False):
     """O = softmax(mask(Q K^T * scale)) V.   q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D] (any batch/head/seq
-    strides, D contiguous), fp16 or bf16, D in {64,128}.  causal is bottom-right aligned.
+    strides, D contiguous), fp16 or bf16, D in {64,128,256}.  causal is bottom-right aligned.
     fast_scale=True (ignored with return_lse) allows the prescaled-Q kernels: ~5 % faster, the scale is
     folded into Q in 16 bit, so the score error grows with the logits (include/star_flash_attn.h)."""
     lib = _lib.load()

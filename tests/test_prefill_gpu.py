@@ -59,32 +59,54 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
     (1, 8, 8, 1024, 1024, 128),
     (1, 2, 2, 1280, 1280, 128),    # 5 q-tiles: two pairs + an unpaired middle tile
     (1, 1, 1, 1800, 1800, 64),     # 8 q-tiles, ragged last tile
+    (2, 4, 2, 1100, 1100, 128),    # several heads per XCD list of the persistent kernel, ragged, GQA
+    (1, 10, 10, 700, 700, 128),    # more heads than XCDs: persistent workgroups walk several units
 ]
 
 
-# every kernel the dispatcher can pick must pass on its own: the 256-row pipelined kernel (one or
-# two q-tile pairs per workgroup) and the 128-row geometry for small grids, each in its exact-scale
-# and its prescaled-Q flavour, the baseline generation kept for A/B runs, and the auto choice
-IMPLS = {"auto": "-1", "rows256": "10", "rows256x2": "10", "rows128": "22", "baseline": "0",
-         "prescaled256": "3", "prescaled256x2": "3", "prescaled128": "21",
-         "x16": "32", "prescaled_x16": "31"}       # the 16x16x32-MFMA kernel, exact / prescaled
+# every kernel the dispatcher can pick must pass on its own: the 4-wave persistent kernel (head_dim 128
+# and 256), the 8-wave 256-row pipelined kernel (one or two q-tile pairs per workgroup) and the 128-row
+# geometry for small grids, each in its exact-scale and its prescaled-Q flavour, and the auto choice.
+# The earlier generations (baseline, 16x16x32 MFMA) live in the A/B build only: tests/test_variants_gpu.py.
+IMPLS = {"auto": -1, "w4": 42, "prescaled_w4": 41, "rows256": 10, "rows256x2": 10, "rows128": 22,
+         "prescaled256": 3, "prescaled256x2": 3, "prescaled128": 21}
+W4_DIMS = (128,)            # head dims the 4-wave kernel serves
+OLD_DIMS = (64, 128)            # ... and the 8-wave / 128-row kernels
 # prescaled kernels carry Q*scale*log2(e) rounded to 16 bit: the log-sum-exp is good to input
 # precision (relative 2^-9 / 2^-12 of the scores), not to the fp32-class 2e-3 of the exact kernels
 LSE_TOL = {"exact": {"bf16": 2e-3, "fp16": 2e-3}, "prescaled": {"bf16": 1.5e-2, "fp16": 4e-3}}
 
 
-def select_impl(monkeypatch, impl):
-    monkeypatch.setenv("SFA_PREFILL_IMPL_DYNAMIC", IMPLS[impl])
-    monkeypatch.setenv("SFA_PREFILL_PAIRS", "2" if impl.endswith("x2") else "1" if impl.endswith("256") else "0")
+@pytest.fixture
+def knobs(sfa):
+    """Kernel-variant selection through sfa_debug_set (the launch paths read no environment variable);
+    everything is back on the library's own choice after the test."""
+    names = ("prefill_impl", "prefill_pairs")
+    yield sfa.debug_set
+    for n in names:
+        sfa.debug_set(n, -1)
+
+
+def select_impl(knobs, impl):
+    knobs("prefill_impl", IMPLS[impl])
+    knobs("prefill_pairs", 2 if impl.endswith("x2") else 1 if impl.endswith("256") else -1)
+
+
+def serves(impl, D):
+    if impl == "auto":
+        return True
+    return D in (W4_DIMS if impl.endswith("w4") else OLD_DIMS)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_hq%d_hkv%d_sq%d_sk%d_d%d" % c)
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("impl", list(IMPLS))
-def test_prefill_vs_oracle(sfa, monkeypatch, case, causal, dtype, impl):
-    select_impl(monkeypatch, impl)
+def test_prefill_vs_oracle(sfa, knobs, case, causal, dtype, impl):
     B, Hq, Hkv, Sq, Sk, D = case
+    if not serves(impl, D):
+        pytest.skip(f"{impl} does not serve head_dim {D}")
+    select_impl(knobs, impl)
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     q = round_to(rng.standard_normal((B, Hq, Sq, D)), dtype)
     k = round_to(rng.standard_normal((B, Hkv, Sk, D)), dtype)
@@ -133,14 +155,14 @@ def test_prefill_strided_layouts_and_out(sfa):
     np.testing.assert_allclose(o3.float().cpu().numpy(), want, atol=2e-3, rtol=2e-3)
 
 
-NON_BASELINE = [i for i in IMPLS if i not in ("auto", "baseline")]
+NON_BASELINE = [i for i in IMPLS if i != "auto"]
 
 
 @pytest.mark.parametrize("impl", NON_BASELINE)
-def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
+def test_prefill_forced_rescale_branch(sfa, knobs, impl):
     """cdna_hip_programming.md rule 26: force the online-softmax max to jump at a chosen tile --
     one K row far larger than the rest, placed late in the sequence, against every Q row."""
-    select_impl(monkeypatch, impl)
+    select_impl(knobs, impl)
     rng = np.random.default_rng(9)
     B, H, S, D = 1, 2, 640, 128
     q = round_to(rng.standard_normal((B, H, S, D)), "bf16")
@@ -157,11 +179,11 @@ def test_prefill_forced_rescale_branch(sfa, monkeypatch, impl):
 
 @pytest.mark.parametrize("impl", NON_BASELINE)
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_prefill_extreme_logits(sfa, monkeypatch, impl, dtype):
+def test_prefill_extreme_logits(sfa, knobs, impl, dtype):
     """Scores two orders of magnitude beyond N(0,1) data (row maxima jump by hundreds of log2 units from
     tile to tile, softmax nearly one-hot): the reference max must move BEFORE any exponential is taken.
     No inf/NaN, and the output matches the fp64 oracle."""
-    select_impl(monkeypatch, impl)
+    select_impl(knobs, impl)
     rng = np.random.default_rng(21)
     B, H, S, D = 1, 2, 700, 128
     q = round_to(6.0 * rng.standard_normal((B, H, S, D)), dtype)
@@ -183,36 +205,11 @@ def test_prefill_extreme_logits(sfa, monkeypatch, impl, dtype):
             assert bad.mean() < 2e-3, bad.mean()
 
 
-@pytest.mark.parametrize("impl", NON_BASELINE)
-def test_prefill_properties_at_bench_size(sfa, monkeypatch, impl):
-    """BASELINE configs 2/3 are too large for the CPU oracle, so check size-independent properties
-    at full size: (1) all-equal V rows -> output equals that row exactly-ish (softmax weights sum
-    to 1); (2) causal output row i depends only on keys <= i: truncating the sequence leaves the
-    first rows bit-identical; (3) a spot-checked slice of heads against the oracle."""
-    select_impl(monkeypatch, impl)
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    B, H, S, D = 2, 4, 4096, 128
-    q, k, v = (torch.randn(B, H, S, D, device=dev).bfloat16() for _ in range(3))
-    vconst = torch.randn(1, 1, 1, D, device=dev).bfloat16().expand(B, H, S, D).contiguous()
-    o = sfa.flash_attn_fwd(q, k, vconst, causal=True)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(o.float().cpu().numpy(), vconst.float().cpu().numpy(), atol=1.6e-2, rtol=1.6e-2)
-    full = sfa.flash_attn_fwd(q, k, v, causal=True)
-    part = sfa.flash_attn_fwd(q[:, :, :1024].contiguous(), k[:, :, :1024].contiguous(),
-                              v[:, :, :1024].contiguous(), causal=True)
-    torch.cuda.synchronize()
-    assert torch.equal(full[:, :, :1024], part)
-    want = sdpa_ref(q[:1, :1].float().cpu().numpy(), k[:1, :1].float().cpu().numpy(),
-                    v[:1, :1].float().cpu().numpy(), causal=True)
-    np.testing.assert_allclose(full[:1, :1].float().cpu().numpy(), want, atol=1.6e-2, rtol=1.6e-2)
-
-
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_prefill_flavours_and_geometries(sfa, monkeypatch, causal, dtype):
-    """Within a numeric flavour the 256-row (1 or 2 pairs per workgroup) and 128-row kernels are
-    bit-identical; the exact flavour is the default, the prescaled one needs fast_scale=True and is
+def test_prefill_flavours_and_geometries(sfa, knobs, causal, dtype):
+    """Within a numeric flavour the 4-wave, the 256-row (1 or 2 pairs per workgroup) and the 128-row kernels
+    are bit-identical (same MFMA order per row, same per-32-row rescale decisions); the exact flavour is the default, the prescaled one needs fast_scale=True and is
     never used when the log-sum-exp is returned."""
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
@@ -220,7 +217,7 @@ def test_prefill_flavours_and_geometries(sfa, monkeypatch, causal, dtype):
     q, k, v = (torch.randn(B, H, S, D, device=dev).to(TDT[dtype]) for _ in range(3))
 
     def run(impl, lse, fast=False):
-        select_impl(monkeypatch, impl)
+        select_impl(knobs, impl)
         r = sfa.flash_attn_fwd(q, k, v, causal=causal, return_lse=lse, fast_scale=fast)
         torch.cuda.synchronize()
         return r[0] if lse else r
@@ -228,9 +225,11 @@ def test_prefill_flavours_and_geometries(sfa, monkeypatch, causal, dtype):
     exact = run("rows256", True)
     assert torch.equal(exact, run("rows256x2", True))
     assert torch.equal(exact, run("rows128", True))
+    assert torch.equal(exact, run("w4", True))
     pre = run("prescaled256", False)
     assert torch.equal(pre, run("prescaled256x2", False))
     assert torch.equal(pre, run("prescaled128", False))
+    assert torch.equal(pre, run("prescaled_w4", False))
     assert torch.equal(run("auto", True), exact) and torch.equal(run("auto", False), exact)   # default: exact
     assert torch.equal(run("auto", False, fast=True), pre)          # opted in, output only -> prescaled Q
     assert torch.equal(run("auto", True, fast=True), exact)         # LSE requested -> exact regardless

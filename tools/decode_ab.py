@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the decode kernel at BASELINE.json configs[3] (B=256 Sq=1 Sk=8192 H=32 D=128 bf16):
-load policy (SFA_DECODE_NT = 0 default, 1 non-temporal) x cache layout (LAYOUTS=blmhd,blhmd,paged:16).
+load policy (knob decode_nt: 0 default, 1 non-temporal) x cache layout (LAYOUTS=blmhd,blhmd,paged:16).
 Usage: [LAYOUTS=blmhd,blhmd] decode_ab.py [nt ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,7 +37,7 @@ for rep in range(2):
             shape = (B, 1, Sk, H, D) if layout == "blmhd" else (B, 1, H, Sk, D)
         k, v = kc.view(shape), vc.view(shape)
         for nt in variants:
-            os.environ["SFA_DECODE_NT"] = str(nt)
+            sfa.debug_set("decode_nt", nt)
             o = torch.empty((B, HQ, D), dtype=torch.bfloat16, device=dev)
             run = lambda: sfa.flash_decode(qkv, z, z, z, k, v, sl, o, B, Sk, HQ, D, D, Sk, 1, 0, **kw)
             for _ in range(2):

@@ -26,7 +26,10 @@ for s in $STEPS; do
     benchfast) run_step bench 300 python bench.py --no-cpu-baseline --no-decode ;;
     prefill) run_step prefill 300 python -u -m pytest tests/test_prefill_gpu.py -m gpu -x -q --timeout 120 ;;
     decode) run_step decode 300 python -u -m pytest tests/test_decode_gpu.py -m gpu -x -q --timeout 120 ;;
-    ab) run_step ab 300 python -u tools/prefill_ab.py ${AB_ARGS:-0 1} ;;
+    ab) run_step ab 300 python -u tools/prefill_ab.py ${AB_ARGS:-1 40} ;;
+    w4) run_step w4 600 python -u -m pytest tests/test_prefill_gpu.py -m gpu -x -q --timeout 120 -k "w4 or flavours" ;;
+    full) run_step full 900 python -u -m pytest tests/test_full_configs_gpu.py -m gpu -x -q --timeout 600 ;;
+    variants) run_step variants 900 env SFA_LIB_PATH=$PWD/starflashattention_amd/lib/libStarFlashAttention_ab.so python -u -m pytest tests -m variants -x -q --timeout 120 ;;
     cmd) run_step cmd ${CMD_TIMEOUT:-300} bash -c "$CMD" < /dev/null ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac

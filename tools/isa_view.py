@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Compress a gfx950 kernel's ISA into one letter per instruction, per basic block.
-usage: tools/isa_view.py file.hip <kernel-substring> [extra hipcc flags]
-M mfma | x v_exp | v other VALU | r ds_read | w ds_write | g global_load | G global_store |
-c s_waitcnt | B s_barrier | s other SALU | p permlane/dpp | j branch | ! scratch"""
+usage: tools/isa_view.py file.hip|file.s <kernel-substring> [extra hipcc flags]
+M mfma | x v_exp | v other VALU | a v_accvgpr_* | L v_readlane/v_writelane (SGPR spill traffic) |
+r ds_read | w ds_write | g global/buffer load | D LDS-DMA | G store | c s_waitcnt | B s_barrier |
+s other SALU | p permlane/dpp | j branch | n s_nop | ! scratch"""
 import re, subprocess, sys
 src, pat = sys.argv[1], sys.argv[2]
 flags = sys.argv[3:]
-asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/root/repo",
-                      "-S", "--cuda-device-only", src, "-o", "-"] + flags, capture_output=True, text=True).stdout
+if src.endswith(".s"):
+    asm = open(src).read()
+else:
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/root/repo",
+                          "-S", "--cuda-device-only", src, "-o", "-"] + flags, capture_output=True, text=True).stdout
 lines = asm.split("\n")
 start = None
 for i, l in enumerate(lines):
-    if re.match(r"^_Z\w*:", l) and pat in l:
+    if re.match(r"^_Z\w*:", l) and all(x in l for x in pat.split("+")):
         start = i
         break
 assert start is not None, "kernel not found"
@@ -34,9 +38,12 @@ for l in lines[start+1:]:
     op = t.split()[0]
     if op.startswith("v_mfma"): c = "M"
     elif op.startswith("v_exp"): c = "x"
+    elif op.startswith("v_accvgpr"): c = "a"
+    elif op.startswith("v_readlane") or op.startswith("v_writelane"): c = "L"
     elif "permlane" in op or "dpp" in t: c = "p"
     elif op.startswith("ds_read") or op.startswith("ds_load"): c = "r"
     elif op.startswith("ds_write") or op.startswith("ds_store"): c = "w"
+    elif (op.startswith("global_load") or op.startswith("buffer_load")) and t.endswith(" lds"): c = "D"
     elif op.startswith("global_load") or op.startswith("buffer_load"): c = "g"
     elif op.startswith("global_store") or op.startswith("buffer_store"): c = "G"
     elif op.startswith("scratch"): c = "!"

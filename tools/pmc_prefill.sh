@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out/pmc; mkdir -p $OUT
-export SFA_PREFILL_IMPL=${IMPL:-1}
+export IMPL=${IMPL:--1}      # tools/prefill_once.py passes it to sfa_debug_set("prefill_impl", ...)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters.txt 2>&1 < /dev/null
 i=0

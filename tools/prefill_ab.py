@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """In-process A/B of the prefill kernels at the headline shape (interleaved rounds; impl numbers:
-prefill_dispatch.hip -- 0 baseline, 1 default (exact scale), 3 prescaled Q, 10 exact forced, 20-22 128-row,
-30-32 16x16x32;
+prefill_dispatch.hip -- -1 auto, 1 8-wave (exact scale), 3 prescaled Q, 10 exact forced, 20-22 128-row,
+40-42 the 4-wave persistent kernel; 0 baseline and 30-32 16x16x32 need the A/B library:
+SFA_LIB_PATH=starflashattention_amd/lib/libStarFlashAttention_ab.so;
 cdna_hip_programming.md rule 24).  usage: python tools/prefill_ab.py [impl ...] [--noncausal] [--d64]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
 
-impls = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0, 1]
+impls = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [1, 40]
 causal = "--noncausal" not in sys.argv
 D = 64 if "--d64" in sys.argv else 128
 B, H, S = 16, 32, 4096
@@ -24,7 +25,7 @@ if "--kvshared" in sys.argv:       # every (batch, head) reads the SAME K/V (str
 outs = {}
 flops = 4.0 * B * H * S * S * D / (2 if causal else 1)
 def run(impl, n):
-    os.environ["SFA_PREFILL_IMPL_DYNAMIC"] = str(impl)
+    sfa.debug_set("prefill_impl", impl)
     o = torch.empty_like(q)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

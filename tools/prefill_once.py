@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
+sfa.debug_set("prefill_impl", int(os.environ.get("IMPL", "-1")))
 B, H, S, D = 16, 32, 4096, 128
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-wave cycle shares of one workgroup's steps 8..15 (SFA_PREFILL_IMPL=4 build).
+"""Diagnostic: per-wave cycle shares of one workgroup's steps 8..15 (prefill_impl 4: the stamping build of the 8-wave kernel).
 Stamps: 0 start of H1, 1 end of H1 (before barrier), 2 after barrier, 3 end of H2."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SFA_PREFILL_IMPL"] = os.environ.get("STAMP_IMPL", "4")
 import torch
 import starflashattention_amd as sfa
+sfa.debug_set("prefill_impl", int(os.environ.get("STAMP_IMPL", "4")))
 B, H, S, D = 16, 32, 4096, 128
 causal = "--noncausal" not in sys.argv
 dev = torch.device("cuda:0")

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic (SFA_PREFILL_IMPL=4 build): where a workgroup's life goes.  Stamps: 0 workgroup start,
+"""Diagnostic (prefill_impl 4: the stamping build of the 8-wave kernel): where a workgroup's life goes.  Stamps: 0 workgroup start,
 1 first q-tile's loop entry (end of the staging prologue), 2 end of the first q-tile's loop, 3 end of
 the workgroup (second q-tile of the pair included).  usage: [--noncausal] [--shape=B,H,S]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SFA_PREFILL_IMPL"] = "4"
 import torch
 import starflashattention_amd as sfa
+sfa.debug_set("prefill_impl", 4)
 B, H, S, D = 16, 32, 4096, 128
 for a in sys.argv[1:]:
     if a.startswith("--shape="):
