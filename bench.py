@@ -5,7 +5,9 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  The batch x heads axis shards embarrassingly: every rank owns its own
+Started without a launcher (WORLD_SIZE unset) and --gpus N > 1, it launches itself: N fresh child
+processes through torch.distributed.run, before this process has touched a GPU; rank 0's JSON line is
+the output.  One process per GPU.  The batch x heads axis shards embarrassingly: every rank owns its own
 B=16 shard (weak scaling) and there is NO collective on the data path -- torch.distributed (RCCL)
 is used only for the two timing barriers and the max-over-ranks reduction of the elapsed time.
 
@@ -17,6 +19,8 @@ Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -114,6 +118,40 @@ def bench_decode(torch, sfa, steps, warmup):
             "head_major_layout": {"achieved": round(gbps_h, 1), "frac": round(gbps_h / PEAK_HBM_GBPS, 4)}}
 
 
+def bench_config5_shard(torch, sfa, steps):
+    """BASELINE.json configs[4]'s per-GPU shard (batch 128 over 8 GPUs = 16 per GPU): S=8192 non-causal."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, H, S, D = 16, 32, 8192, 128
+    g = torch.Generator(device=dev).manual_seed(77)
+    q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev, dtype=torch.float32).bfloat16() for _ in range(3))
+    out = torch.empty_like(q)
+    for _ in range(3):
+        sfa.flash_attn_fwd(q, k, v, causal=False, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        sfa.flash_attn_fwd(q, k, v, causal=False, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    tf = attn_flops(B, H, S, S, D, False) / (ms * 1e-3) / 1e12
+    return {"workload": "prefill fwd full, B=16 H=32 S=8192 D=128 (BASELINE.json configs[4], one GPU's shard)",
+            "ms_per_step": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start N fresh ranks (torch.distributed.run) and relay their output.
+    Nothing in THIS process has touched a GPU yet (torch is not even imported), and it is never replaced by
+    exec: the ranks are children, this process exits with their code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +162,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import starflashattention_amd as sfa
@@ -186,12 +226,14 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = None, None
-        try:                    # committed PMC measurement of this same command (tools/profile_bench.sh)
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-                traffic = json.load(f)["prefill_kernel"]["total_bytes"]
-                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
-        except Exception:
-            pass
+        for name in ("r02_hbm_traffic.json",):      # committed PMC measurement of this same command (tools/profile_bench.sh)
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["prefill_kernel"]["total_bytes"]
+                    traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+                break
+            except Exception:
+                pass
         rec = {
             "metric": "attention fwd TFLOPS/GPU (% MFMA peak), bf16 seqlen=4096 hdim=128",
             "value": round(total_tflops, 2), "unit": "TFLOPS",
@@ -205,7 +247,7 @@ def main():
                        "causal": causal, "parallelism": f"batch-shard x{world}"},
             "tflops_per_gpu": round(total_tflops / world, 2),
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "prefill_kernel<Bf16,128,causal>",
+            "roofline": {"bound": "mfma", "kernel": "prefill_w4_kernel<Bf16,128,causal,exact>",
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
@@ -233,6 +275,11 @@ def main():
             try:
                 del q, k, v, out
                 torch.cuda.empty_cache()
+                rec["config5_shard"] = bench_config5_shard(torch, sfa, min(20, max(3, args.steps // 4)))
+                torch.cuda.empty_cache()
+            except Exception as e:
+                rec["config5_shard"] = {"error": repr(e)[:200]}
+            try:
                 rec["decode_roofline"] = bench_decode(torch, sfa, min(50, max(3, args.steps // 2)), 3)
             except Exception as e:                      # the headline number must still print
                 rec["decode_roofline"] = {"error": repr(e)[:200]}

@@ -37,6 +37,8 @@
 // inserts the wait states; (2) a VALU-written VGPR used as an MFMA operand needs two wait states -- the
 // packed P registers are written at least one slot before their PV MFMA, and the first MFMA behind any
 // freshly written operand carries an `s_nop 1`.
+#include <utility>
+
 #include "prefill_core.h"
 
 namespace sfa {
@@ -50,17 +52,17 @@ namespace w4 {
 constexpr int kRows = 256;          // query rows per workgroup (q-tile)
 constexpr int kKeys = 64;           // keys per K/V tile
 constexpr int kThreadsW4 = 256;     // 4 waves, one per SIMD
-constexpr int kRing = 3;            // LDS ring depth of K and of V
 constexpr float kThr = 8.0f;        // lazy-rescale threshold (log2 units)
 
 // LDS image of one [64 keys][D] 16-bit tile: 8-row groups of D/32 sub-tiles of 8 rows x 64 B.
 //   off(row, ch) = RG*(row>>3) + 512*(ch>>2) + 64*(row&7) + 16*((ch&3) ^ ((row>>2)&3))      (ch = 16-B chunk of the row)
-template <int D> struct Img {
+// RING tiles of K, then RING tiles of V (RING = 3: the DMA of a tile has one tile time to land; 4: two).
+template <int D, int RING = 3> struct Img {
     static constexpr int RG = 512 * (D / 32);       // bytes of one 8-row group
     static constexpr int TILE = 8 * RG;             // 64 rows
     static constexpr int K_BASE = 0;
-    static constexpr int V_BASE = kRing * TILE;
-    static constexpr int TOTAL = 2 * kRing * TILE;
+    static constexpr int V_BASE = RING * TILE;
+    static constexpr int TOTAL = 2 * RING * TILE;
 };
 
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
@@ -109,20 +111,33 @@ __device__ __forceinline__ void dma_piece(unsigned lds, unsigned voff, u32x4s sr
                  :: "s"(lds), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
-template <int D, int NQB>
+// s[r] = -inf where key kbase + (r&3) + 8*(r>>2) + 4*h2 lies beyond `lim`: one subtract per call, then a compare
+// against a literal and a select per register (prefill_core.h's mask_half builds sixteen key indices first, and
+// hipcc hoists those out of the rare branch into the MFMA gaps).
+__device__ __forceinline__ void mask_keys(f32x16 &s, int kbase, int h2, int lim) {
+    const int room = lim - kbase - 4 * h2;              // keys with offset <= room stay
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) > room) s[r] = ninf();
+}
+
+// Per-wave online-softmax state of the two query blocks.
+template <int D>
 struct Acc {
-    f32x16 o[NQB][D / 32];      // O^T accumulators (AGPRs)
-    float msc[NQB];             // reference max the exponentials are taken against (log2 units)
-    float lsum[NQB];            // this lane's share of the running row sum
-    f32x16 cinit[NQB];          // prescaled flavour: -msc in all 16 registers (C operand of the first QK^T MFMA)
+    f32x16 o[2][D / 32];        // O^T accumulators (AGPRs)
+    float msc[2];               // reference max the exponentials are taken against (log2 units)
+    float msafe[2];             // msc, or 0 while a row has seen no key yet (what the scale/subtract uses)
+    float lsum[2];              // this lane's share of the running row sum
+    float alpha[2];             // a rescale of O decided but not yet applied (see hstep); 1 = none
+    uint32_t pk[2][8];          // P^T of the half-tile being consumed, packed: pk[q][4k .. 4k+3] = B operand of k-step k
+    f32x16 cinit[2];            // prescaled flavour: -msc in all 16 registers (C operand of the first QK^T MFMA)
 };
 
-// O, the row sum, (prescaled: the pending scores and cinit) move to a new reference max.  Rare.
-template <int D, int NQB>
-__device__ __forceinline__ void rescale_o(Acc<D, NQB> &acc, int q, float alpha) {
+// O moves to a new reference max.  Rare.
+template <int D>
+__device__ __forceinline__ void rescale_o(Acc<D> &acc, int q, float alpha) {
 #pragma unroll
     for (int d = 0; d < D / 32; ++d) settle_acc(acc.o[q][d]);       // PV MFMAs of the previous half-step may be in flight
-    acc.lsum[q] *= alpha;
 #pragma unroll
     for (int d = 0; d < D / 32; ++d)
 #pragma unroll
@@ -131,232 +146,275 @@ __device__ __forceinline__ void rescale_o(Acc<D, NQB> &acc, int q, float alpha) 
 
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-// One pipelined half-step in explicit slot order, for both query blocks of the wave (prefill_core.h's
-// h_block on this kernel's register files and LDS image):
-//   sN[q] <- scores of K rows [32*HN, +32) of the tile at kbuf                      (DO_QK; NKS*NQB MFMAs)
-//   sO[q]  = scores of keys [32*HO, +32) of the tile whose V is at vbuf: row max finished (slot 0),
-//            exponentiated in place, packed to 16 bit, O^T += V^T . P^T            (NPV*NQB MFMAs)
-// lds: the workgroup's LDS; k_e / v_e: this lane's read offsets (ks even / e = 0; the odd twins are ^32);
-// kbuf / vbuf / kbuf_pref: ring offsets.
-template <class Tr, int D, int NQB, int PF, int ORD, int HN, int HO, bool DO_QK, bool PREF, class QkHook = NoHook,
-          class PvHook = NoHook, int PH = 1 - HN>
-__device__ __forceinline__ void half_step(const lds_char *lds, unsigned k_e, unsigned v_e, int kbuf, int vbuf, int kbuf_pref,
-                                          const typename Tr::mfma_vec (&qf)[NQB][D / 16], f32x16 (&sN)[NQB],
-                                          f32x16 (&sO)[NQB], Acc<D, NQB> &acc, float c2, const float (&mxO)[NQB],
-                                          float (&mxN)[NQB], int mask_o, int kbase_o, int h2, const int (&lim)[NQB],
-                                          typename Tr::mfma_vec (&kpre)[PF], const QkHook &qk_hook = QkHook(),
-                                          const PvHook &pv_hook = PvHook()) {
+// ---- the element pipeline ----------------------------------------------------------------------
+// One wave alone on its SIMD hides work behind an MFMA only in the gap right behind THAT MFMA, and only about
+// one v_exp + three plain VALU + one LDS read of it (tools/micro/mfma_overlap.hip: M f M f with 3 VALU + 1 exp
+// + 1 ds_read per gap = 34.7 cycles per MFMA; the same fillers bunched behind a PAIR of MFMAs = 59).  So a
+// half-step is 32 GAPS -- one MFMA each -- and the softmax of a half-tile is cut into per-ELEMENT stages that
+// are dealt out one per gap:
+//     F  s = s * c2 - msafe        (exact flavour only)
+//     X  s = exp2(s)
+//     A  lsum += s; every second element: pack the pair to 16 bit
+// The 32 score registers a lane holds for a half-tile (2 query blocks x 16) are walked in the order their PV
+// MFMAs need them: element i -> block i>>3 = (k-step, query block) in the order (0,q0) (0,q1) (1,q0) (1,q1),
+// register 8*kstep + (i&7).  X of element i runs in gap i - 8, F one gap earlier, A one gap later: the first
+// eight elements (block (0,q0)) are exponentiated in the LAST eight gaps of the half-step that computed them.
+// MFMA order: QK^T query-block-major (gaps 0-7 q0, 8-15 q1: q0's scores are complete half-way through), then
+// PV in the block order above (gaps 16-19, 20-23, 24-27, 28-31).
+// Row max of the NEW scores: q0 in gaps 9-16 (decision in gap 17), q1 in gaps 17-24 (decision in gap 25).
+// A decision to move the reference max (rare) takes effect at once for msc / msafe / lsum -- every row-sum
+// add under the old reference is over by then -- but O still has PV MFMAs of the old reference ahead of it, so
+// the factor is parked in acc.alpha and applied at the entry of the NEXT half-step (`pend`).
+// LDS reads, one per gap, each at least eight gaps ahead of its MFMA: the 16 transposed V reads in gaps 0-15,
+// the eight K fragments of the NEXT half-step in gaps 16-23 (kpre).
+//
+// State at entry (and at exit, for sN): elements 0..7 exponentiated, 0..6 summed, pairs 0..2 packed, element 8
+// scaled.  lead_in() establishes it for the first half-tile of a q-tile; hstep_last() consumes the last one.
+constexpr int kLead = 8;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every register index in
+// the gap program must be a constant (a runtime-indexed f32x16 goes to scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ constexpr int el_q(int i) { return (i >> 3) & 1; }
+__device__ __forceinline__ constexpr int el_r(int i) { return 8 * (i >> 4) + (i & 7); }
+
+// The stages are inline asm: a volatile asm statement keeps its place among the (volatile asm) MFMAs, whereas
+// plain arithmetic floats -- instruction selection had bunched ten v_exp at the top of a block and left most
+// MFMA gaps with nothing but their LDS read.  hipcc still allocates every register.
+template <class Tr, int ORD, int I>
+__device__ __forceinline__ void st_f(f32x16 (&s)[2], const float (&msafe)[2], float c2) {
+    if constexpr (ORD != 6 && I >= 0 && I < 32)
+        asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(s[el_q(I)][el_r(I)]) : "s"(c2), "v"(msafe[el_q(I)]));
+}
+template <int I>
+__device__ __forceinline__ void st_x(f32x16 (&s)[2]) {
+    if constexpr (I >= 0 && I < 32) asm volatile("v_exp_f32 %0, %0" : "+v"(s[el_q(I)][el_r(I)]));
+}
+template <class Tr, int I>
+__device__ __forceinline__ void st_a(f32x16 (&s)[2], float (&lsum)[2], uint32_t (&pk)[2][8]) {
+    if constexpr (I >= 0 && I < 32) {
+        constexpr int q = el_q(I), r = el_r(I);
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(lsum[q]) : "v"(s[q][r]));
+        if constexpr (I & 1) {
+            if constexpr (Tr::id == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[q][r >> 1]) : "v"(s[q][r - 1]), "v"(s[q][r]));
+            else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[q][r >> 1]) : "v"(s[q][r - 1]), "v"(s[q][r]));
+        }
+    }
+}
+// m = max(m, a, b), in place among the MFMAs (and without the canonicalising v_max hipcc puts in front of fmaxf)
+__device__ __forceinline__ void st_max3(float &m, const float &a, const float &b) {
+    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b));
+}
+
+// The reference max of query block q against freshly computed scores s (masked if need be): decide, and if it
+// moves, move msc / msafe / lsum now and park the factor for O.  Exact flavour: s are raw Q.K^T; prescaled: s
+// are already relative to msc in log2 units and move with it.
+template <class Tr, int D, int ORD>
+__device__ __forceinline__ void decide(Acc<D> &acc, int q, f32x16 &s, float mxl, float c2, int &pend) {
+    if (ORD == 6) {
+        if (__any(mxl > kThr)) {
+            const float d = fmaxf(half_max(mxl), 0.f);          // rows that did not rise keep their reference
+            const float al = fast_exp2(-d);
+            acc.msc[q] += d;
+            acc.lsum[q] *= al;
+            acc.alpha[q] = al;
+            pend = 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] -= d; acc.cinit[q][r] = -acc.msc[q]; }
+        }
+        return;
+    }
+    // (a row's two lanes share msc, so the trigger needs no cross-lane exchange)
+    if (__any(mxl * c2 > acc.msc[q] + kThr)) {                  // rare after the first tiles
+        const float mx = half_max(mxl) * c2;                    // both lane halves hold the same query
+        const float mnew = fmaxf(acc.msc[q], mx);
+        const float al = (mnew == ninf()) ? 1.0f : fast_exp2(acc.msc[q] - mnew);
+        acc.msc[q] = mnew;
+        acc.lsum[q] *= al;
+        acc.alpha[q] = al;
+        pend = 1;
+    }
+    acc.msafe[q] = (acc.msc[q] == ninf()) ? 0.f : acc.msc[q];
+}
+
+// Apply the rescales of O decided during the previous half-step (wave-uniform, rare).
+template <int D>
+__device__ __forceinline__ void apply_pending(Acc<D> &acc, int &pend) {
+    if (pend) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { rescale_o<D>(acc, q, acc.alpha[q]); acc.alpha[q] = 1.0f; }
+        pend = 0;
+    }
+}
+
+// First half-tile of a q-tile: its scores s were just computed outside the pipeline.  Sets the reference max
+// outright and brings s into the entry state of hstep().
+template <class Tr, int D, int ORD>
+__device__ __forceinline__ void lead_in(Acc<D> &acc, f32x16 (&s)[2], float c2, int mask, int h2, const int (&lim)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        settle(s[q]);
+        if (mask & (1 << q)) mask_keys(s[q], 0, h2, lim[q]);
+        const float mx = half_max(lane_rowmax(s[q]));
+        if (ORD == 6) {
+            const float m0 = (mx == ninf()) ? 0.f : mx;
+            acc.msc[q] = m0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[q][r] -= m0; acc.cinit[q][r] = -m0; }
+        } else {
+            acc.msc[q] = mx * c2;
+            acc.msafe[q] = (mx == ninf()) ? 0.f : acc.msc[q];
+        }
+    }
+    static_for<kLead + 1>([&](auto ic) { st_f<Tr, ORD, decltype(ic)::value>(s, acc.msafe, c2); });
+    static_for<kLead>([&](auto ic) { st_x<decltype(ic)::value>(s); });
+    static_for<kLead - 1>([&](auto ic) { st_a<Tr, decltype(ic)::value>(s, acc.lsum, acc.pk); });
+}
+
+// One pipelined half-step of 32 gaps (see above):
+//   sN <- scores of K rows [32*HN, +32) of the tile at kbuf, both query blocks          (gaps 0-15)
+//   sO  = scores of keys [32*HO, +32) of the tile whose V is at vbuf, in the entry state: finished,
+//         O^T += V^T . P^T                                                              (gaps 16-31)
+//   and sN is left in the entry state for the next half-step.
+// mask_n bit q: sN[q] holds keys that must be masked (diagonal / ragged tiles); kbase_n = their first key.
+// kpre[PF] in: the first PF K fragments of this half-step; out (PREF): those of the next one (rows
+// [32*PH, +32) of the tile at kbuf_pref).  hook(n): extra work for gap n (the LDS-DMA pieces of H2).
+// ABL (diagnostic builds only, results wrong by construction): 4 = no softmax stages, 8 = no LDS fragment reads.
+template <class Tr, int D, int PF, int ORD, int HN, int HO, bool PREF, int PH, int ABL = 0, class Hook = NoHook>
+__device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigned v_e, int kbuf, int vbuf, int kbuf_pref,
+                                      const typename Tr::mfma_vec (&qf)[2][D / 16], f32x16 (&sN)[2], f32x16 (&sO)[2],
+                                      Acc<D> &acc, int &pend, float c2, int mask_n, int kbase_n, int h2,
+                                      const int (&lim)[2], typename Tr::mfma_vec (&kpre)[PF], const Hook &hook = Hook()) {
     using Vec = typename Tr::mfma_vec;
-    constexpr int NKS = D / 16, NDB = D / 32, NPV = 2 * NDB;
+    constexpr int NKS = D / 16, NDB = D / 32;
     constexpr int RG = Img<D>::RG;
     constexpr bool PS = (ORD == 6);
-    static_assert(NKS >= 8, "the staged softmax below assumes >= 8 QK slots (head_dim >= 128)");
+    static_assert(NKS == 8 && NDB == 4 && PF == 8, "the gap program below is written for head_dim 128");
 
     const lds_char *const kb_e = lds + (k_e + kbuf), *const kb_o = lds + ((k_e ^ 32) + kbuf);
     const lds_char *const vb_0 = lds + (v_e + vbuf), *const vb_1 = lds + ((v_e ^ 32) + vbuf);
     const lds_char *const kp_e = lds + (k_e + kbuf_pref), *const kp_o = lds + ((k_e ^ 32) + kbuf_pref);
     auto ld_k = [&](int ks) -> Vec {        // rows 32*HN + (lane & 31), chunk 2*ks + h2
-        const lds_char *b = (ks & 1) ? kb_o : kb_e;
-        return bitcast<Vec>(lds_read16(b + 4 * RG * HN + 512 * (ks >> 1)));
+        return bitcast<Vec>(lds_read16(((ks & 1) ? kb_o : kb_e) + 4 * RG * HN + 512 * (ks >> 1)));
     };
     auto ld_kp = [&](int ks) -> Vec {
-        const lds_char *b = (ks & 1) ? kp_o : kp_e;
-        return bitcast<Vec>(lds_read16(b + 4 * RG * PH + 512 * (ks >> 1)));
+        return bitcast<Vec>(lds_read16(((ks & 1) ? kp_o : kp_e) + 4 * RG * PH + 512 * (ks >> 1)));
     };
-    auto ld_v = [&](int j) -> Vec {         // A operand of PV MFMAs j: d block j % NDB, k-step j / NDB of this half
+    // transposed read e (0 / 1) of V fragment j (A operand of the PV MFMAs of d block j % 4, k-step j / 4)
+    auto ld_vt = [&](int j, int e) -> u32x2 {
         const int d = j % NDB, s = 2 * HO + j / NDB;
-        const i16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vb_0 + RG * (2 * s) + 512 * d));
-        const i16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vb_1 + RG * (2 * s + 1) + 512 * d));
+        return bitcast<u32x2>(__builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_i16x4 *)((e ? vb_1 : vb_0) + RG * (2 * s + e) + 512 * d)));
+    };
+
+    apply_pending<D>(acc, pend);
+
+    Vec kf[NKS];
+    u32x2 vlo[2 * NDB], vhi[2 * NDB];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) kf[i] = kpre[i];
+    asm volatile("" :: "v"(kf[NKS - 1]));   // one wait for all eight K fragments (read >= 8 gaps ago), see the gap loop
+    float m0 = ninf(), m1 = ninf();         // lane max of the new scores, q0 / q1
+    static_for<32>([&](auto ic) {
+        constexpr int n = decltype(ic)::value;
+        // ---- the MFMA of this gap ----
+        if constexpr (n < 16) {
+            constexpr int q = n >> 3, ks = n & 7;
+            if constexpr (ks == 0) {
+                if constexpr (PS) mfma_qk_first_c<Tr>(sN[q], kf[0], qf[q][0], acc.cinit[q]);
+                else mfma_qk_first<Tr>(sN[q], kf[0], qf[q][0]);
+            } else {
+                mfma_qk<Tr>(sN[q], kf[ks], qf[q][ks]);
+            }
+        } else {
+            constexpr int blk = (n - 16) >> 2, d = (n - 16) & 3, q = blk & 1, ks = blk >> 1, j = NDB * ks + d;
+            u32x4 av, pv;
+            av[0] = vlo[j][0]; av[1] = vlo[j][1]; av[2] = vhi[j][0]; av[3] = vhi[j][1];
+            pv[0] = acc.pk[q][4 * ks + 0]; pv[1] = acc.pk[q][4 * ks + 1];
+            pv[2] = acc.pk[q][4 * ks + 2]; pv[3] = acc.pk[q][4 * ks + 3];
+            mfma_pv<Tr, false>(acc.o[q][d], bitcast<Vec>(av), bitcast<Vec>(pv));
+        }
+        // ---- one LDS read ----
+        if constexpr (ABL & 8) {
+            if constexpr (n == 0) {
+#pragma unroll
+                for (int i = PF; i < NKS; ++i) kf[i] = kf[i & 1];
+#pragma unroll
+                for (int i = 0; i < 2 * NDB; ++i) { vlo[i] = bitcast<u32x4>(kf[0]).xy; vhi[i] = bitcast<u32x4>(kf[1]).xy; }
+            }
+        } else if constexpr (n < 16) {
+            if constexpr (n & 1) vhi[n >> 1] = ld_vt(n >> 1, 1);
+            else vlo[n >> 1] = ld_vt(n >> 1, 0);
+        } else if constexpr (n < 16 + NKS && PREF) kpre[n - 16] = ld_kp(n - 16);
+        // One s_waitcnt per batch of fragments instead of one per MFMA (each costs an issue slot of the gap):
+        // naming the YOUNGEST read of a batch makes hipcc wait for the whole batch here, and every batch was
+        // issued at least eight gaps ago.
+        if constexpr (!(ABL & 8)) {
+            if constexpr (n == 15) asm volatile("" :: "v"(vhi[NDB - 1]));
+            if constexpr (n == 23) asm volatile("" :: "v"(vhi[2 * NDB - 1]));
+        }
+        // ---- softmax stages of the half-tile being consumed ----
+        if constexpr (!(ABL & 4)) {
+        if constexpr (n == 0) st_a<Tr, kLead - 1>(sO, acc.lsum, acc.pk);
+        st_f<Tr, ORD, n + kLead + 1>(sO, acc.msafe, c2);
+        st_x<n + kLead>(sO);
+        if constexpr (n >= 1) st_a<Tr, n + kLead - 1>(sO, acc.lsum, acc.pk);
+        }
+        // ---- row max of the new scores, and their lead stages ----
+        if constexpr (n == 9) { if (mask_n & 1) mask_keys(sN[0], kbase_n, h2, lim[0]); }     // wave-uniform, diagonal / ragged tiles only
+        if constexpr (n >= 9 && n <= 16) st_max3(m0, sN[0][2 * (n - 9)], sN[0][2 * (n - 9) + 1]);
+        if constexpr (n == 17) {
+            decide<Tr, D, ORD>(acc, 0, sN[0], m0, c2, pend);
+            if (mask_n & 2) mask_keys(sN[1], kbase_n, h2, lim[1]);
+        }
+        if constexpr (n >= 17 && n <= 24) st_max3(m1, sN[1][2 * (n - 17)], sN[1][2 * (n - 17) + 1]);
+        if constexpr (n == 25) decide<Tr, D, ORD>(acc, 1, sN[1], m1, c2, pend);
+        if constexpr (!(ABL & 4)) {
+        if constexpr (n >= 23) st_f<Tr, ORD, n - 23>(sN, acc.msafe, c2);         // elements 0..8
+        if constexpr (n >= 24) st_x<n - 24>(sN);                                 // elements 0..7
+        if constexpr (n >= 25) st_a<Tr, n - 25>(sN, acc.lsum, acc.pk);           // elements 0..6
+        }
+        hook(n);
+        SFA_FENCE();
+    });
+}
+
+// Last half-step of a q-tile for this wave: no new scores.  Finishes sO (entry state) and adds its P.V.
+template <class Tr, int D, int ORD, int HO>
+__device__ __forceinline__ void hstep_last(const lds_char *lds, unsigned v_e, int vbuf, f32x16 (&sO)[2], Acc<D> &acc,
+                                           int &pend, float c2) {
+    using Vec = typename Tr::mfma_vec;
+    constexpr int NDB = D / 32;
+    constexpr int RG = Img<D>::RG;
+    const lds_char *const vb_0 = lds + (v_e + vbuf), *const vb_1 = lds + ((v_e ^ 32) + vbuf);
+    apply_pending<D>(acc, pend);
+    Vec vf[2 * NDB];
+#pragma unroll
+    for (int j = 0; j < 2 * NDB; ++j) {
+        const int d = j % NDB, s = 2 * HO + j / NDB;
+        const u32x2 lo = bitcast<u32x2>(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vb_0 + RG * (2 * s) + 512 * d)));
+        const u32x2 hi = bitcast<u32x2>(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(vb_1 + RG * (2 * s + 1) + 512 * d)));
         u32x4 av;
-        const u32x2 a_lo = bitcast<u32x2>(t0), a_hi = bitcast<u32x2>(t1);
-        av[0] = a_lo[0]; av[1] = a_lo[1]; av[2] = a_hi[0]; av[3] = a_hi[1];
-        return bitcast<Vec>(av);
-    };
-
-    Vec kf[NKS], vf[NPV];
-    // ---- slot 0: first QK MFMAs next to the finish of sO's row max ----
-    if (DO_QK) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) kf[i] = kpre[i];
-        static_assert(PF < NKS, "the K fragments of a half-step outnumber the prefetch distance");
-        kf[PF] = ld_k(PF);
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            if (PS) mfma_qk_first_c<Tr>(sN[q], kf[0], qf[q][0], acc.cinit[q]);
-            else mfma_qk_first<Tr>(sN[q], kf[0], qf[q][0]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) vf[i] = ld_v(i);
+        av[0] = lo[0]; av[1] = lo[1]; av[2] = hi[0]; av[3] = hi[1];
+        vf[j] = bitcast<Vec>(av);
     }
-    if (PS && DO_QK) {          // stage X of the first pair already in slot 0
-#pragma unroll
-        for (int q = 0; q < NQB; ++q)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) sO[q][e] = fast_exp2(sO[q][e]);
-    }
-    float msafe[NQB] = {};
-#pragma unroll
-    for (int q = 0; q < NQB && !PS; ++q) {
-        float mxl = mxO[q];
-        if (mask_o & (1 << q)) {                        // wave-uniform, diagonal / ragged tiles only
-            mask_half(sO[q], kbase_o, h2, lim[q]);
-            mxl = lane_rowmax(sO[q]);
-        }
-        // (a row's two lanes share msc, so the trigger needs no cross-lane exchange)
-        if (__any(mxl * c2 > acc.msc[q] + kThr)) {      // rare after the first tiles
-            const float mx = half_max(mxl) * c2;        // both lane halves hold the same query
-            const float mnew = fmaxf(acc.msc[q], mx);
-            const float alpha = (mnew == ninf()) ? 1.0f : fast_exp2(acc.msc[q] - mnew);
-            acc.msc[q] = mnew;
-            rescale_o<D, NQB>(acc, q, alpha);
-        }
-        msafe[q] = (acc.msc[q] == ninf()) ? 0.f : acc.msc[q];
-    }
-    SFA_FENCE();
-
-    uint32_t pk[NQB][8];                    // P^T packed: pk[q][4k .. 4k+3] is the B operand of k-step k
-    float rs0[NQB], rs1[NQB];
-#pragma unroll
-    for (int q = 0; q < NQB; ++q) { rs0[q] = 0.f; rs1[q] = 0.f; }
-    auto soft1 = [&](int e) {               // element e of every query block; packs completed pairs
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            sO[q][e] = PS ? fast_exp2(sO[q][e]) : fast_exp2(fmaf(sO[q][e], c2, -msafe[q]));
-            if (e & 1) { rs1[q] += sO[q][e]; pk[q][e >> 1] = Tr::pack2(sO[q][e - 1], sO[q][e]); }
-            else { rs0[q] += sO[q][e]; }
-        }
-    };
-    // The softmax work software-pipelined across slots in three stages per element pair -- F
-    // (scale+subtract), X (v_exp), A (row sum + pack) -- so no instruction sits right behind the one it
-    // depends on.  Pair g (elements 2g, 2g+1) does F in soft-slot g, X in g+1, A in g+2; soft-slot u is QK
-    // slot u+1 for u < NKS-1 and PV slot u-(NKS-1) after that (pairs 0..3 must be packed before the first
-    // PV MFMA, pairs 4..7 before PV slot NPV/2).  Prescaled flavour: two stages (X, A).
-    auto stage_f = [&](int g) {
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            sO[q][2 * g] = fmaf(sO[q][2 * g], c2, -msafe[q]);
-            sO[q][2 * g + 1] = fmaf(sO[q][2 * g + 1], c2, -msafe[q]);
-        }
-    };
-    auto stage_x = [&](int g) {
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            sO[q][2 * g] = fast_exp2(sO[q][2 * g]);
-            sO[q][2 * g + 1] = fast_exp2(sO[q][2 * g + 1]);
-        }
-    };
-    auto stage_a = [&](int g) {
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            rs0[q] += sO[q][2 * g];
-            rs1[q] += sO[q][2 * g + 1];
-            pk[q][g] = Tr::pack2(sO[q][2 * g], sO[q][2 * g + 1]);
-        }
-    };
-    auto staged_slot = [&](int u) {
-        if (PS) {
-            const int w = u + 1;            // (slot 0 already did X of pair 0)
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (g + 1 == w) stage_a(g);
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (g == w) stage_x(g);
-            return;
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-            if (g + 2 == u) stage_a(g);
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-            if (g + 1 == u) stage_x(g);
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-            if (g == u) stage_f(g);
-    };
-
-    if (DO_QK) {
-#pragma unroll
-        for (int i = 1; i < NKS; ++i) {
-            if (i + PF < NKS) kf[i + PF] = ld_k(i + PF); else vf[i + PF - NKS] = ld_v(i + PF - NKS);
-#pragma unroll
-            for (int q = 0; q < NQB; ++q) mfma_qk<Tr>(sN[q], kf[i], qf[q][i]);
-            staged_slot(i - 1);
-            qk_hook(i);
-            SFA_FENCE();
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) soft1(e);
-        SFA_FENCE();
-    }
-    float m0[NQB], m1[NQB];
-#pragma unroll
-    for (int q = 0; q < NQB; ++q) { m0[q] = ninf(); m1[q] = ninf(); }
-    constexpr int EP = 16 / NPV;            // elements per early PV slot (no-QK form)
-    constexpr int EM = 32 / NPV;            // new scores max-ed per late PV slot
-#pragma unroll
-    for (int j = 0; j < NPV; ++j) {
-        if (j + PF < NPV) {
-            vf[j + PF] = ld_v(j + PF);
-        } else if (PREF) {                  // last PF slots: first K fragments of the next half-step
-            kpre[j + PF - NPV] = ld_kp(j + PF - NPV);
-        }
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            uint4 w;
-            w.x = pk[q][4 * (j / NDB) + 0]; w.y = pk[q][4 * (j / NDB) + 1];
-            w.z = pk[q][4 * (j / NDB) + 2]; w.w = pk[q][4 * (j / NDB) + 3];
-            // the P registers of a k-step are packed in the slot right before its first MFMA
-            if (q == 0 && (j % NDB) == 0) mfma_pv<Tr, true>(acc.o[q][j % NDB], vf[j], bitcast<Vec>(w));
-            else mfma_pv<Tr, false>(acc.o[q][j % NDB], vf[j], bitcast<Vec>(w));
-        }
-        if (DO_QK) {
-            staged_slot(NKS - 1 + j);
-        } else if (j < NPV / 2) {
-#pragma unroll
-            for (int e = 0; e < EP; ++e) soft1(8 + EP * j + e);
-        }
-        if (j >= NPV / 2 && DO_QK) {        // lane max of the new scores (their MFMAs ended >= NPV/2 slots ago)
-#pragma unroll
-            for (int q = 0; q < NQB; ++q)
-#pragma unroll
-                for (int e = 0; e < EM; e += 4) {
-                    const int r = EM * (j - NPV / 2) + e;
-                    m0[q] = max3(m0[q], sN[q][r], sN[q][r + 1]);
-                    m1[q] = max3(m1[q], sN[q][r + 2], sN[q][r + 3]);
-                }
-        }
-        pv_hook(j);
-        SFA_FENCE();
-    }
-#pragma unroll
-    for (int q = 0; q < NQB; ++q) {
-        acc.lsum[q] += rs0[q] + rs1[q];
-        if (!PS) mxN[q] = fmaxf(m0[q], m1[q]);
-    }
-    if (PS && DO_QK) {
-        // prescaled: finish the row max of the NEW scores now (already relative to msc, log2 units), so msc
-        // is final before the next half-step's first MFMA reads cinit
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            float mxl = fmaxf(m0[q], m1[q]);
-            if ((mask_o >> q) & 1) {
-                mask_half(sN[q], kbase_o, h2, lim[q]);
-                mxl = lane_rowmax(sN[q]);
-            }
-            if (__any(mxl > kThr)) {
-                const float mx = half_max(mxl);
-                const float d = fmaxf(mx, 0.f);         // rows that did not rise keep their reference
-                const float alpha = fast_exp2(-d);
-                acc.msc[q] += d;
-                rescale_o<D, NQB>(acc, q, alpha);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sN[q][r] -= d; acc.cinit[q][r] = -acc.msc[q]; }
-            }
-        }
-    }
+    st_a<Tr, kLead - 1>(sO, acc.lsum, acc.pk);
+    static_for<32>([&](auto ic) { if constexpr (decltype(ic)::value > kLead) st_f<Tr, ORD, decltype(ic)::value>(sO, acc.msafe, c2); });
+    static_for<32>([&](auto ic) { if constexpr (decltype(ic)::value >= kLead) st_x<decltype(ic)::value>(sO); });
+    static_for<32>([&](auto ic) { if constexpr (decltype(ic)::value >= kLead) st_a<Tr, decltype(ic)::value>(sO, acc.lsum, acc.pk); });
+    static_for<16>([&](auto ic) {
+        constexpr int m = decltype(ic)::value, blk = m >> 2, d = m & 3, q = blk & 1, ks = blk >> 1;
+        u32x4 pv;
+        pv[0] = acc.pk[q][4 * ks + 0]; pv[1] = acc.pk[q][4 * ks + 1];
+        pv[2] = acc.pk[q][4 * ks + 2]; pv[3] = acc.pk[q][4 * ks + 3];
+        mfma_pv<Tr, m == 0>(acc.o[q][d], vf[NDB * ks + d], bitcast<Vec>(pv));
+    });
 }
 
 }  // namespace w4
@@ -373,17 +431,18 @@ struct W4Cursor {
     bool live;
 };
 
-template <class Tr, int D, bool CAUSAL, int ORD>
+template <class Tr, int D, bool CAUSAL, int ORD, int RING, int DIAG, int DMA_AT = 0>
 __global__ void __launch_bounds__(w4::kThreadsW4, 1)
 prefill_w4_kernel(const PrefillKernelParams p) {
     using namespace w4;
     using Vec = typename Tr::mfma_vec;
-    constexpr int NQB = 2, PF = 2;
+    constexpr int NQB = 2, PF = 8;
     constexpr bool PS = (ORD == 6);
-    constexpr int PSO = PS ? 32 : 0;
     constexpr int NKS = D / 16, NDB = D / 32;
     constexpr int NJ = D / 64;                  // 128-byte column pieces per row
-    using L = Img<D>;
+    using L = Img<D, RING>;
+    constexpr int NDMA = 4 * NJ;                // LDS-DMA pieces a wave issues per step (K tile + V tile)
+    static_assert(RING == 3 || RING == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -468,19 +527,27 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         d.lo = lo;
         d.left -= tileb;
     };
-    auto issue_tile = [&](const Desc &d, bool is_k, int ring_off) {
+    // the buffer descriptor of a tile; `live` false (the producer has run out of tiles): zero bytes, so the
+    // pieces still issue -- no branch in the MFMA gaps -- and simply zero-fill a ring slot nobody will read
+    auto make_srd = [&](const Desc &d, bool live) -> u32x4s {
         u32x4s srd;
         srd[0] = d.lo;
         srd[1] = d.hi & 0xffffu;
-        srd[2] = (unsigned)max(d.left, 0);
+        srd[2] = live ? (unsigned)max(d.left, 0) : 0u;
         srd[3] = 0x00020000u;
+        return srd;
+    };
+    // piece idx (0 .. 2*NJ-1) of this wave's share of a tile: row group idx / NJ, column piece idx % NJ
+    auto issue_piece = [&](const u32x4s &srd, bool is_k, int ring_off, int idx) {
+        const int half = idx / NJ, j = idx % NJ;
         const unsigned dst = lds0 + (is_k ? L::K_BASE : L::V_BASE) + ring_off + 2 * wave * L::RG;
+        if (DIAG & 2) return;                   // timing-only ablation: no LDS-DMA
+        dma_piece(dst + half * L::RG + 1024 * j, is_k ? (half ? kvoff1 : kvoff0) : (half ? vvoff1 : vvoff0), srd, 128u * j);
+    };
+    auto issue_tile = [&](const Desc &d, bool is_k, int ring_off) {
+        const u32x4s srd = make_srd(d, true);
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                dma_piece(dst + half * L::RG + 1024 * j, is_k ? (half ? kvoff1 : kvoff0) : (half ? vvoff1 : vvoff0), srd,
-                          128u * j);
+        for (int idx = 0; idx < 2 * NJ; ++idx) issue_piece(srd, is_k, ring_off, idx);
     };
 
     // ---- this lane's LDS read bases (the odd twins are ^32) ----
@@ -499,15 +566,44 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     first_item(pc, true);
     Desc kd = {0, 0, 0}, vd = {0, 0, 0}, vpend = {0, 0, 0};
     bool vpend_live = false;
+    bool thin_tail = false;                     // the last produce_k() had nothing left to issue
     if (pc.live) { kd = desc_at_head(true, pc.b, pc.h); vd = desc_at_head(false, pc.b, pc.h); }
     int kring_p = 0, vring_p = 0;               // ring byte offsets the producers write next
-    auto ring_next = [](int x) -> int { return x == (kRing - 1) * L::TILE ? 0 : x + L::TILE; };
+    auto ring_next = [](int x) -> int { return x == (RING - 1) * L::TILE ? 0 : x + L::TILE; };
     auto produce_v = [&]() {                    // V of the stream position K produced last time
         if (vpend_live) issue_tile(vpend, false, vring_p);
         vring_p = kring_p;
     };
+    // the same, one piece per call (spread over the MFMA gaps of H2): V pieces first, then K pieces
+    u32x4s piece_srd = {0, 0, 0, 0};            // descriptor of the tile whose pieces are being dealt out
+    auto produce_v_piece = [&](int idx) {
+        if (idx == 0) piece_srd = make_srd(vpend, vpend_live);
+        issue_piece(piece_srd, false, vring_p, idx);
+        if (idx == 2 * NJ - 1) vring_p = kring_p;
+    };
+    auto k_advance = [&]() {
+        vpend = vd;
+        if (++pc.t < pc.nt) {
+            desc_advance(kd, k_tileb);
+            desc_advance(vd, v_tileb);
+        } else {
+            next_item(pc, true);
+            if (pc.live) { kd = desc_at_head(true, pc.b, pc.h); vd = desc_at_head(false, pc.b, pc.h); }
+        }
+    };
+    auto produce_k_piece = [&](int idx) {
+        if (idx == 0) piece_srd = make_srd(kd, pc.live);
+        issue_piece(piece_srd, true, kring_p, idx);
+        if (idx == 2 * NJ - 1) {
+            vpend_live = pc.live;
+            thin_tail = !pc.live;
+            if (pc.live) k_advance();
+            kring_p = ring_next(kring_p);
+        }
+    };
     auto produce_k = [&]() {
         vpend_live = pc.live;
+        thin_tail = !pc.live;
         if (pc.live) {
             issue_tile(kd, true, kring_p);
             vpend = vd;
@@ -521,14 +617,36 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         }
         kring_p = ring_next(kring_p);
     };
-    // stream prologue: K(0), K(1), V(0) must be visible before the first step; K(2), V(1) in flight
+    // Before the barrier of a step the pieces issued behind the PREVIOUS barrier must have landed.  Ring 3:
+    // those are the youngest ones -> vmcnt(0).  Ring 4: one more step's pieces may stay in flight ->
+    // vmcnt(NDMA), as long as that younger step really issued all of its pieces (it does not once the
+    // producer has run out of tiles: then drain).  Ops hipcc issues in between (Q loads, O stores) are
+    // younger than the pieces waited for, so they only make the wait stricter.
+    auto wait_and_sync = [&]() {
+        if (DIAG & 16) return;                  // timing-only ablation: no wait, no barrier
+        if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDMA) : "memory");
+    };
+    // DIAG: one workgroup stamps s_memtime at five points of steps 8..15 of its first item into p.lse (as
+    // u64[wave][step][8]); the stamp drains lgkmcnt, so read SHARES from it, not absolute speed.
+    auto stamp = [&](int step, int which) {
+        if ((DIAG & 1) && blockIdx.x == 8 && step >= 8 && step < 16 && p.lse) {
+            unsigned long long tm;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+            if (lane == 0) reinterpret_cast<unsigned long long *>(p.lse)[(wave * 8 + (step - 8)) * 8 + which] = tm;
+        }
+    };
+    // stream prologue: K(0), K(1), V(0) must be visible before the first step; the rest in flight
     produce_k(); produce_v(); produce_k(); produce_v(); produce_k();
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (RING == 4) { produce_v(); produce_k(); }
+    thin_tail = !pc.live && !vpend_live;
+    if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * NDMA) : "memory");
 
     int kcur = 0, vcur = 0;                     // ring byte offsets of the compute's current tile
 #define SFA_W4_SYNC_AND_STAGE()                                                                     \
     do {                                                                                            \
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                               \
+        wait_and_sync();                                                                            \
         produce_v();                                                                                \
         produce_k();                                                                                \
     } while (0)
@@ -578,7 +696,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             return m;
         };
 
-        Acc<D, NQB> acc;
+        Acc<D> acc;
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
 #pragma unroll
@@ -586,20 +704,22 @@ prefill_w4_kernel(const PrefillKernelParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc.o[q][d][r] = 0.f;
             acc.msc[q] = PS ? 0.f : ninf();
+            acc.msafe[q] = 0.f;
             acc.lsum[q] = 0.f;
+            acc.alpha[q] = 1.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc.pk[q][i] = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc.cinit[q][r] = 0.f;
         }
+        int pend = 0;                                           // a rescale of O is parked in acc.alpha (wave-uniform)
 
-        // ---- scores of the first half-tile, first fragments of the second ----
+        // ---- scores of the first half-tile (outside the pipeline), first fragments of the second ----
         f32x16 sA[NQB], sB[NQB];
-        float mxA[NQB], mxB[NQB];
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            mxA[q] = ninf(); mxB[q] = ninf();
+        for (int q = 0; q < NQB; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sA[q][r] = 0.f; sB[q][r] = 0.f; }
-        }
         Vec kpre[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) kpre[i] = bitcast<Vec>(make_uint4(0, 0, 0, 0));
@@ -617,53 +737,46 @@ prefill_w4_kernel(const PrefillKernelParams p) {
 #pragma unroll
             for (int i = 0; i < PF; ++i)
                 kpre[i] = bitcast<Vec>(lds_read16(((i & 1) ? kb_o : kb_e) + 4 * L::RG + 512 * (i >> 1)));
-#pragma unroll
-            for (int q = 0; q < NQB; ++q) {
-                settle(sA[q]);
-                mxA[q] = lane_rowmax(sA[q]);
-                if (PS) {           // the first half-tile sets the reference outright (scores may sit far below 0)
-                    if (mask_bits(0) & (1 << q)) {
-                        mask_half(sA[q], 0, h2, lim[q]);
-                        mxA[q] = lane_rowmax(sA[q]);
-                    }
-                    const float mx = half_max(mxA[q]);
-                    const float m0 = (mx == ninf()) ? 0.f : mx;
-                    acc.msc[q] = m0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { sA[q][r] -= m0; acc.cinit[q][r] = -m0; }
-                }
-            }
+            lead_in<Tr, D, ORD>(acc, sA, c2, mask_bits(0), h2, lim);
         }
 
         int t = 0;
-        // ---- FULL steps: this wave needs the next tile as well.  The DMA pieces of K(t+3) and V(t+2) ride in
-        // the QK slots of H2, right behind the barrier that freed their ring slots.
-        //   H1(t): QK^T(B_t)     || max,exp(A_t),   PV(A_t) || lane max(B_t)
-        //   H2(t): QK^T(A_{t+1}) || max,exp(B_t),   PV(B_t) || lane max(A_{t+1})
+        // ---- FULL steps: this wave needs the next tile as well.  A and B are the score registers of the two
+        // 32-key halves of a tile; each half-step computes one and consumes the other:
+        //   H1(t): S(B_t) = K(t)[32:64] Q^T     || softmax(A_t), O += P(A_t) V(t)[0:32]
+        //   barrier(t)            -- K(t+2), V(t+1) visible; the slots of K(t), V(t-1) free
+        //   H2(t): S(A_t+1) = K(t+1)[0:32] Q^T  || softmax(B_t), O += P(B_t) V(t)[32:64] || LDS-DMA of K(t+3), V(t+2)
         for (; t + 1 < ntw; ++t) {
             const int k1 = ring_next(kcur);
             const int kbase = t * kKeys;
-            half_step<Tr, D, NQB, PF, ORD, 1, 0, true, true>(lds, k_e, v_e, kcur, vcur, k1, qf, sB, sA, acc, c2, mxA, mxB,
-                                                            mask_bits(kbase + PSO), kbase + PSO, h2, lim, kpre);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            auto dma_hook = [&](int i) {
-                if (i == 1) produce_v();
-                if (i == 4) produce_k();
+            stamp(t, 0);
+            hstep<Tr, D, PF, ORD, 1, 0, true, 0, DIAG & 12>(lds, k_e, v_e, kcur, vcur, k1, qf, sB, sA, acc, pend, c2,
+                                                 mask_bits(kbase + 32), kbase + 32, h2, lim, kpre);
+            stamp(t, 1);
+            if (DIAG & 1) {
+                if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+                stamp(t, 2);
+            }
+            wait_and_sync();
+            stamp(t, 3);
+            auto dma_hook = [&](int n) {                        // one piece per gap, from gap DMA_AT on
+                if (n >= DMA_AT && n < DMA_AT + 2 * NJ) produce_v_piece(n - DMA_AT);
+                else if (n >= DMA_AT + 2 * NJ && n < DMA_AT + 4 * NJ) produce_k_piece(n - DMA_AT - 2 * NJ);
             };
-            half_step<Tr, D, NQB, PF, ORD, 0, 1, true, true>(lds, k_e, v_e, k1, vcur, k1, qf, sA, sB, acc, c2, mxB, mxA,
-                                                            mask_bits(kbase + 32 + PSO), kbase + 32 + PSO, h2, lim, kpre,
-                                                            dma_hook);
+            hstep<Tr, D, PF, ORD, 0, 1, true, 1, DIAG & 12>(lds, k_e, v_e, k1, vcur, k1, qf, sA, sB, acc, pend, c2,
+                                                 mask_bits(kbase + 64), kbase + 64, h2, lim, kpre, dma_hook);
+            stamp(t, 4);
             kcur = k1;
             vcur = ring_next(vcur);
         }
         // ---- TAIL step: this wave's last tile (its second half computes no new scores) ----
         if (t < ntw) {
             const int kbase = t * kKeys;
-            half_step<Tr, D, NQB, PF, ORD, 1, 0, true, false>(lds, k_e, v_e, kcur, vcur, kcur, qf, sB, sA, acc, c2, mxA, mxB,
-                                                             mask_bits(kbase + PSO), kbase + PSO, h2, lim, kpre);
+            hstep<Tr, D, PF, ORD, 1, 0, false, 0>(lds, k_e, v_e, kcur, vcur, kcur, qf, sB, sA, acc, pend, c2,
+                                                  mask_bits(kbase + 32), kbase + 32, h2, lim, kpre);
             SFA_W4_SYNC_AND_STAGE();
-            half_step<Tr, D, NQB, PF, ORD, 0, 1, false, false>(lds, k_e, v_e, kcur, vcur, kcur, qf, sA, sB, acc, c2, mxB, mxA,
-                                                              mask_bits(kbase + 32), kbase + 32, h2, lim, kpre);
+            hstep_last<Tr, D, ORD, 1>(lds, v_e, vcur, sB, acc, pend, c2);
             kcur = ring_next(kcur);
             vcur = ring_next(vcur);
             ++t;
@@ -700,27 +813,29 @@ prefill_w4_kernel(const PrefillKernelParams p) {
 #undef SFA_W4_SYNC_AND_STAGE
 }
 
-template <class Tr, int D, int ORD>
+template <class Tr, int D, int ORD, int RING, int DIAG, int DMA_AT = 0>
 int launch_w4_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     using namespace w4;
-    const int lds = Img<D>::TOTAL;
+    const int lds = Img<D, RING>::TOTAL;
     // one workgroup per CU, fewer when the XCD lists are shorter than 32 units
     const int nq = (p.Sq + kRows - 1) / kRows;
     const long long units_xcd = (long long)p.bh_per_xcd * (causal ? (nq + 1) / 2 : nq);
     const int nslots = (int)(units_xcd < 32 ? units_xcd : 32);
     dim3 grid(8u * nslots), block(kThreadsW4);
     static DynLdsAttr attr_c, attr_f;
-    if (const int rc = causal ? attr_c.ensure(reinterpret_cast<const void *>(&prefill_w4_kernel<Tr, D, true, ORD>), lds,
+    if (const int rc = causal ? attr_c.ensure(reinterpret_cast<const void *>(&prefill_w4_kernel<Tr, D, true, ORD, RING, DIAG, DMA_AT>), lds,
                                               "prefill_w4_kernel")
-                              : attr_f.ensure(reinterpret_cast<const void *>(&prefill_w4_kernel<Tr, D, false, ORD>), lds,
+                              : attr_f.ensure(reinterpret_cast<const void *>(&prefill_w4_kernel<Tr, D, false, ORD, RING, DIAG, DMA_AT>), lds,
                                               "prefill_w4_kernel"))
         return rc;
-    if (causal) hipLaunchKernelGGL((prefill_w4_kernel<Tr, D, true, ORD>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((prefill_w4_kernel<Tr, D, false, ORD>), grid, block, lds, stream, p);
+    if (causal) hipLaunchKernelGGL((prefill_w4_kernel<Tr, D, true, ORD, RING, DIAG, DMA_AT>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((prefill_w4_kernel<Tr, D, false, ORD, RING, DIAG, DMA_AT>), grid, block, lds, stream, p);
     return check_launch("prefill_w4_kernel");
 }
 
 }  // namespace
+
+constexpr int kW4Ring = 3;          // shipped LDS ring depth (3 or 4)
 
 // force: 0 = flavour by policy (exact unless the caller opted into fast_scale), 1 = prescaled, 2 = exact
 int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream, int force) {
@@ -732,10 +847,25 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     const long long k_ext = (long long)(p.Sk - 1) * 2 * p.ks[2] + 2 * head_dim, v_ext = (long long)(p.Sk - 1) * 2 * p.vs[2] + 2 * head_dim;
     if (k_ext >= (1ll << 31) || v_ext >= (1ll << 31) || p.ks[2] * 2 >= (1ll << 24) || p.vs[2] * 2 >= (1ll << 24))
         return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: one head's K/V rows span more than 2 GiB");
+    // force 3 / 4: the other ring depth / the stamping build (bf16, exact) -- A/B and diagnostics only
+    if (force == 3) return launch_w4_t<Bf16, 128, 2, 7 - kW4Ring, 0>(p, causal, stream);
+    if (force == 4) return launch_w4_t<Bf16, 128, 2, kW4Ring, 1>(p, causal, stream);
+#ifdef SFA_WITH_VARIANTS      // timing-only ablations (results wrong by construction): the A/B library only
+    if (force == 5) return launch_w4_t<Bf16, 128, 2, kW4Ring, 2>(p, causal, stream);     // no LDS-DMA
+    if (force == 6) return launch_w4_t<Bf16, 128, 2, kW4Ring, 4>(p, causal, stream);     // no softmax stages
+    if (force == 7) return launch_w4_t<Bf16, 128, 2, kW4Ring, 8>(p, causal, stream);     // no LDS fragment reads
+    if (force == 8) return launch_w4_t<Bf16, 128, 2, kW4Ring, 16>(p, causal, stream);    // no barrier
+    if (force == 9) return launch_w4_t<Bf16, 128, 2, kW4Ring, 30>(p, causal, stream);    // MFMAs only
+    if (force == 10) return launch_w4_t<Bf16, 128, 2, 3, 0, 24>(p, causal, stream);      // DMA pieces in the last gaps of H2
+    if (force == 11) return launch_w4_t<Bf16, 128, 2, 4, 0, 24>(p, causal, stream);
+    if (force == 12) return launch_w4_t<Bf16, 128, 2, 4, 0, 16>(p, causal, stream);
+#endif
     const bool prescaled = force == 0 ? p.fast_scale != 0 : force == 1;
     if (dtype == SFA_DTYPE_FP16)
-        return prescaled ? launch_w4_t<Fp16, 128, 6>(p, causal, stream) : launch_w4_t<Fp16, 128, 2>(p, causal, stream);
-    return prescaled ? launch_w4_t<Bf16, 128, 6>(p, causal, stream) : launch_w4_t<Bf16, 128, 2>(p, causal, stream);
+        return prescaled ? launch_w4_t<Fp16, 128, 6, kW4Ring, 0>(p, causal, stream)
+                         : launch_w4_t<Fp16, 128, 2, kW4Ring, 0>(p, causal, stream);
+    return prescaled ? launch_w4_t<Bf16, 128, 6, kW4Ring, 0>(p, causal, stream)
+                     : launch_w4_t<Bf16, 128, 2, kW4Ring, 0>(p, causal, stream);
 }
 
 }  // namespace sfa

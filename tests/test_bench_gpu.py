@@ -1,0 +1,45 @@
+"""bench.py's own multi-rank path: `python bench.py --gpus 2` with no launcher starts two
+fresh ranks itself (torch.distributed.run children), barriers, takes the max over ranks and prints ONE JSON
+line from rank 0.  On the one-GPU test box both ranks share the device (SFA_BENCH_BACKEND=gloo: the
+rendezvous and the timing path are the product's, only RCCL is swapped for gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra, env=None):
+    e = dict(os.environ, **(env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--no-decode", "--no-cpu-baseline", *extra],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launch():
+    rec = run_bench("--gpus", "2", env={"SFA_BENCH_BACKEND": "gloo"})
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["config"]["global_batch"] == 32 and rec["scaling"] == "weak"
+    assert rec["unit"] == "TFLOPS" and rec["dtype"] == "bf16" and rec["vs_baseline"] is None
+    # two ranks time-share one GPU here: the aggregate is about one GPU's rate, not two
+    assert 100.0 < rec["value"] < 2 * 2500.0
+    assert abs(rec["tflops_per_gpu"] * 2 - rec["value"]) < 0.02 * rec["value"]
+
+
+def test_bench_single_rank_line():
+    rec = run_bench()
+    assert rec["n_gpus"] == 1 and rec["config"]["global_batch"] == 16
+    rf = rec["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 100.0 < rec["value"] < 2500.0

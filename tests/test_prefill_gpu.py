@@ -208,8 +208,8 @@ def test_prefill_extreme_logits(sfa, knobs, impl, dtype):
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_prefill_flavours_and_geometries(sfa, knobs, causal, dtype):
-    """Within a numeric flavour the 4-wave, the 256-row (1 or 2 pairs per workgroup) and the 128-row kernels
-    are bit-identical (same MFMA order per row, same per-32-row rescale decisions); the exact flavour is the default, the prescaled one needs fast_scale=True and is
+    """Within a numeric flavour the 256-row (1 or 2 pairs per workgroup) and the 128-row kernels are
+    bit-identical (same MFMA order per row, same per-32-row rescale decisions); the exact flavour is the default, the prescaled one needs fast_scale=True and is
     never used when the log-sum-exp is returned."""
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
@@ -225,16 +225,18 @@ def test_prefill_flavours_and_geometries(sfa, knobs, causal, dtype):
     exact = run("rows256", True)
     assert torch.equal(exact, run("rows256x2", True))
     assert torch.equal(exact, run("rows128", True))
-    assert torch.equal(exact, run("w4", True))
     pre = run("prescaled256", False)
     assert torch.equal(pre, run("prescaled256x2", False))
     assert torch.equal(pre, run("prescaled128", False))
-    assert torch.equal(pre, run("prescaled_w4", False))
     assert torch.equal(run("auto", True), exact) and torch.equal(run("auto", False), exact)   # default: exact
     assert torch.equal(run("auto", False, fast=True), pre)          # opted in, output only -> prescaled Q
     assert torch.equal(run("auto", True, fast=True), exact)         # LSE requested -> exact regardless
-    # the two flavours differ by 16-bit rounding flips only
+    # the 4-wave kernel sums each row in a different order (one accumulator per query block, elements in PV
+    # order): the same flavours to a 16-bit rounding flip, not to the bit
     tol = TOL[dtype]
+    np.testing.assert_allclose(run("w4", True).float().cpu().numpy(), exact.float().cpu().numpy(), atol=tol / 2, rtol=tol / 2)
+    np.testing.assert_allclose(run("prescaled_w4", False).float().cpu().numpy(), pre.float().cpu().numpy(), atol=tol / 2, rtol=tol / 2)
+    # the two flavours differ by 16-bit rounding flips only
     np.testing.assert_allclose(pre.float().cpu().numpy(), exact.float().cpu().numpy(), atol=tol, rtol=tol)
 
 
