@@ -182,7 +182,7 @@ typedef struct sfa_prefill_args {
     int heads_kv;
     int seqlen_q;
     int seqlen_k;
-    int head_dim;                   /* 64 or 128                                      */
+    int head_dim;                   /* 64, 128 or 256                                 */
     int64_t q_stride[3];            /* {batch, head, seq} strides in elements         */
     int64_t k_stride[3];
     int64_t v_stride[3];

@@ -258,8 +258,8 @@ int sfa_prefill_fwd(const sfa_prefill_args *a, void *stream) {
                     a->batch, a->heads_q, a->heads_kv, a->seqlen_q, a->seqlen_k);
     if (a->heads_q % a->heads_kv)
         return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: heads_q=%d not a multiple of heads_kv=%d", a->heads_q, a->heads_kv);
-    if (a->head_dim != 64 && a->head_dim != 128)
-        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: head_dim %d not in {64, 128}", a->head_dim);
+    if (a->head_dim != 64 && a->head_dim != 128 && a->head_dim != 256)
+        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: head_dim %d not in {64, 128, 256}", a->head_dim);
     if (a->dtype != SFA_DTYPE_FP16 && a->dtype != SFA_DTYPE_BF16)
         return fail(SFA_ERR_BAD_DTYPE, "sfa_prefill_fwd: dtype %d is not fp16(0)/bf16(1)", a->dtype);
     const int64_t *st[4] = {a->q_stride, a->k_stride, a->v_stride, a->o_stride};

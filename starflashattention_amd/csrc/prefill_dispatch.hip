@@ -1,8 +1,10 @@
 // Picks the prefill kernel.
+//   head_dim 256: prefill_d256_kernel.hip, always.
 //   auto (default), head_dim 128:
 //     the 4-wave persistent kernel (prefill_w4_kernel.hip: one wave per SIMD, 64 query rows per wave,
 //     O^T in the accumulator file, K/V by LDS-DMA, 256 persistent workgroups) whenever the problem
-//     has enough 256-row q-tiles to feed the 256 CUs;
+//     has enough 256-row q-tiles to feed the 256 CUs (and, under the causal mask, rows long enough to amortise
+//     its per-q-tile fixed costs: the rule and its measurements are in launch_prefill below);
 //   otherwise:
 //     the 8-wave 256-row software-pipelined kernel (prefill_kernel.hip) whenever the problem has enough of
 //     its workgroups (a pair of 256-row q-tiles each) for about half the 256 CUs; smaller problems take the
@@ -23,13 +25,18 @@
 namespace sfa {
 
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
+    if (head_dim == 256) return launch_prefill_d256(p, dtype, causal, stream);      // its own (only) kernel
     int which = g_knobs.prefill_impl.load(std::memory_order_relaxed);
     if (which < 0) {
         const long long nq = (p.Sq + 255) / 256;
         const long long qtiles = (long long)p.B * p.Hq * nq;
-        if (head_dim == 256) {
-            which = 40;                 // the only geometry with 256-wide heads
-        } else if (head_dim == 128 && qtiles >= kW4MinTiles) {
+        // Measured crossover of the 4-wave persistent kernel against the best of the other two
+        // (tools/prefill_crossover.sh): full attention from 256 q-tiles on (+5..20 %); under the causal
+        // mask only long rows pay -- 16 q-tiles per head and 2048 in all, or 32 per head and 1024 in all
+        // (+2..5 %; at seqlen 2048 and below its per-q-tile fixed costs lose 5..15 %).
+        const bool w4 = head_dim == 128 && (causal ? ((nq >= 16 && qtiles >= 2048) || (nq >= 32 && qtiles >= 1024))
+                                                   : qtiles >= kW4MinTiles);
+        if (w4) {
             which = 40;
         } else {
             // the 8-wave kernel runs one workgroup per PAIR of q-tiles.  Measured crossover
@@ -47,8 +54,6 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
         return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d needs the A/B build of the library (build_lib(variants=True))", which);
 #endif
     if (which >= 40 && which <= 59) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
-    if (head_dim != 64 && head_dim != 128)
-        return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: head_dim %d needs the 4-wave kernel", head_dim);
     if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);

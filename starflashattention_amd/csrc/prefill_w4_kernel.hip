@@ -155,6 +155,8 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 //     F  s = s * c2 - msafe        (exact flavour only)
 //     X  s = exp2(s)
 //     A  lsum += s; every second element: pack the pair to 16 bit
+// (Row sums on the matrix pipe instead -- a fifth MFMA per PV block with an all-ones A operand, no v_add in any
+// gap -- measured SLOWER: 965 vs 1005 TFLOPS causal; the register file is full and the pipe gets 12.5 % more work.)
 // The 32 score registers a lane holds for a half-tile (2 query blocks x 16) are walked in the order their PV
 // MFMAs need them: element i -> block i>>3 = (k-step, query block) in the order (0,q0) (0,q1) (1,q0) (1,q1),
 // register 8*kstep + (i&7).  X of element i runs in gap i - 8, F one gap earlier, A one gap later: the first
@@ -297,12 +299,8 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
     constexpr bool PS = (ORD == 6);
     static_assert(NKS == 8 && NDB == 4 && PF == 8, "the gap program below is written for head_dim 128");
 
-    const lds_char *const kb_e = lds + (k_e + kbuf), *const kb_o = lds + ((k_e ^ 32) + kbuf);
     const lds_char *const vb_0 = lds + (v_e + vbuf), *const vb_1 = lds + ((v_e ^ 32) + vbuf);
     const lds_char *const kp_e = lds + (k_e + kbuf_pref), *const kp_o = lds + ((k_e ^ 32) + kbuf_pref);
-    auto ld_k = [&](int ks) -> Vec {        // rows 32*HN + (lane & 31), chunk 2*ks + h2
-        return bitcast<Vec>(lds_read16(((ks & 1) ? kb_o : kb_e) + 4 * RG * HN + 512 * (ks >> 1)));
-    };
     auto ld_kp = [&](int ks) -> Vec {
         return bitcast<Vec>(lds_read16(((ks & 1) ? kp_o : kp_e) + 4 * RG * PH + 512 * (ks >> 1)));
     };
@@ -428,7 +426,7 @@ struct W4Cursor {
     int sub;            // causal: 0 = the heavy q-tile of the pair, 1 = the light one
     int t, nt;          // tile inside the item, tiles of the item
     int b, h, qt;       // batch, head, q-tile
-    bool live;
+    int live;           // (int: a struct copy with padding bytes goes through scratch)
 };
 
 template <class Tr, int D, bool CAUSAL, int ORD, int RING, int DIAG, int DMA_AT = 0>
@@ -442,6 +440,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     constexpr int NJ = D / 64;                  // 128-byte column pieces per row
     using L = Img<D, RING>;
     constexpr int NDMA = 4 * NJ;                // LDS-DMA pieces a wave issues per step (K tile + V tile)
+    constexpr int NQLD = NQB * NKS;             // global loads load_q() issues per lane (all unconditional)
     static_assert(RING == 3 || RING == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -542,6 +541,10 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         const int half = idx / NJ, j = idx % NJ;
         const unsigned dst = lds0 + (is_k ? L::K_BASE : L::V_BASE) + ring_off + 2 * wave * L::RG;
         if (DIAG & 2) return;                   // timing-only ablation: no LDS-DMA
+        if (DIAG & 32) {                        // timing-only ablation: everything but the load itself
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst + half * L::RG + 1024 * j), "v"(kvoff0), "s"(srd), "s"(128u * j) : "memory");
+            return;
+        }
         dma_piece(dst + half * L::RG + 1024 * j, is_k ? (half ? kvoff1 : kvoff0) : (half ? vvoff1 : vvoff0), srd, 128u * j);
     };
     auto issue_tile = [&](const Desc &d, bool is_k, int ring_off) {
@@ -622,8 +625,16 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     // vmcnt(NDMA), as long as that younger step really issued all of its pieces (it does not once the
     // producer has run out of tiles: then drain).  Ops hipcc issues in between (Q loads, O stores) are
     // younger than the pieces waited for, so they only make the wait stricter.
+    // wait_and_sync_q(): the same right behind load_q() -- its NQLD loads are the youngest vector-memory
+    // operations of the wave and must not be waited for (they are wanted a q-tile later)
+    auto wait_and_sync_q = [&]() {
+        if (DIAG & 16) return;
+        if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NQLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDMA + NQLD) : "memory");
+    };
     auto wait_and_sync = [&]() {
         if (DIAG & 16) return;                  // timing-only ablation: no wait, no barrier
+        if (DIAG & 64) { asm volatile("s_barrier" ::: "memory"); return; }     // timing-only ablation: barrier, no wait for the pieces
         if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDMA) : "memory");
     };
@@ -659,21 +670,37 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (long long)min(qrow, p.Sq - 1) * p.qs[2] + 8 * h2;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                u32x4 w = bitcast<u32x4>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
-                if (PS) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = Tr::pack2(Tr::lo_f32(w[i]) * c2, Tr::hi_f32(w[i]) * c2);
-                }
-                qf[q][ks] = bitcast<Vec>(w);
+                qf[q][ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
             }
         }
     };
+    // prescaled flavour: fold scale * log2(e) into Q once per q-tile, when the rows are first needed (not where
+    // they are requested: that would wait for the loads on the spot)
+    auto prescale_q = [&]() {
+        if (!PS) return;
+#pragma unroll
+        for (int q = 0; q < NQB; ++q)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                u32x4 w = bitcast<u32x4>(qf[q][ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = Tr::pack2(Tr::lo_f32(w[i]) * c2, Tr::hi_f32(w[i]) * c2);
+                qf[q][ks] = bitcast<Vec>(w);
+            }
+    };
 
+    // Requesting the NEXT item's Q rows under the current item's last half-step (DIAG 128) measured no better than
+    // loading them at the start of their own item: -1..-2 % causal, +0.5 % full (same-run A/B); off.
+    constexpr bool QPRE = (DIAG & 128) != 0;
+    if (cc.live && QPRE) load_q(cc.b, cc.h, cc.qt);
     while (cc.live) {
         const int qt = cc.qt, nt = cc.nt;
         const int b = cc.b, h = cc.h;
-        load_q(b, h, qt);
-        // Q^T now sits in the accumulator file; two wait states between the moves and the first MFMA
+        if (!QPRE) load_q(b, h, qt);
+        prescale_q();
+        W4Cursor nx;                            // the item after this one (set where its Q rows are requested: exactly
+                                                // one of the two places below runs per item)
+        // Q^T sits in the accumulator file (hipcc waits for the loads here); two wait states before the first MFMA
 #pragma unroll
         for (int q = 0; q < NQB; ++q)
 #pragma unroll
@@ -687,12 +714,16 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             const int qrow = wq0 + 32 * q + l31;
             lim[q] = CAUSAL ? min(p.Sk - 1, qrow + coff) : p.Sk - 1;
         }
-        // bit q set: the 32 keys starting at kbase need masking for query block q (wave-uniform)
+        // bit q set: the 32 keys starting at kbase need masking for query block q (wave-uniform): kbase lies
+        // beyond the last half-tile that block sees whole -- one threshold per block and q-tile
+        int whole[NQB];
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) whole[q] = CAUSAL ? min(wq0 + 32 * q + coff - 31, p.Sk - 32) : p.Sk - 32;
         auto mask_bits = [&](int kbase) -> int {
             int m = 0;
 #pragma unroll
             for (int q = 0; q < NQB; ++q)
-                if ((CAUSAL && (kbase + 31 > wq0 + 32 * q + coff)) || (kbase + 32 > p.Sk)) m |= 1 << q;
+                if (kbase > whole[q]) m |= 1 << q;
             return m;
         };
 
@@ -775,11 +806,25 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             const int kbase = t * kKeys;
             hstep<Tr, D, PF, ORD, 1, 0, false, 0>(lds, k_e, v_e, kcur, vcur, kcur, qf, sB, sA, acc, pend, c2,
                                                   mask_bits(kbase + 32), kbase + 32, h2, lim, kpre);
-            SFA_W4_SYNC_AND_STAGE();
+            nx = cc;                                            // this item's last QK^T MFMA has been issued: request the
+            next_item(nx, false);                               // next item's Q rows under the last half-step, the idle
+            if (nx.live && QPRE) {                              // steps and the epilogue
+                load_q(nx.b, nx.h, nx.qt);
+                wait_and_sync_q();
+            } else {
+                wait_and_sync();
+            }
+            produce_v();
+            produce_k();
             hstep_last<Tr, D, ORD, 1>(lds, v_e, vcur, sB, acc, pend, c2);
             kcur = ring_next(kcur);
             vcur = ring_next(vcur);
             ++t;
+        }
+        if (ntw == 0) {                                         // (a wave without any tile of its own in this item)
+            nx = cc;
+            next_item(nx, false);
+            if (nx.live && QPRE) load_q(nx.b, nx.h, nx.qt);
         }
         // ---- idle steps (causal: tiles beyond this wave's diagonal): keep staging for the others ----
         for (; t < nt; ++t) {
@@ -805,7 +850,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
                 }
             }
         }
-        next_item(cc, false);
+        cc = nx;
     }
     // drain: DMA pieces issued for stream positions nobody consumes do not exist (the producers stop at the
     // end of the list), but the last steps' pieces must have landed before the workgroup's LDS is released
@@ -857,8 +902,11 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (force == 8) return launch_w4_t<Bf16, 128, 2, kW4Ring, 16>(p, causal, stream);    // no barrier
     if (force == 9) return launch_w4_t<Bf16, 128, 2, kW4Ring, 30>(p, causal, stream);    // MFMAs only
     if (force == 10) return launch_w4_t<Bf16, 128, 2, 3, 0, 24>(p, causal, stream);      // DMA pieces in the last gaps of H2
-    if (force == 11) return launch_w4_t<Bf16, 128, 2, 4, 0, 24>(p, causal, stream);
-    if (force == 12) return launch_w4_t<Bf16, 128, 2, 4, 0, 16>(p, causal, stream);
+    if (force == 11) return launch_w4_t<Bf16, 128, 2, kW4Ring, 32>(p, causal, stream);   // no load instruction, all else kept
+    if (force == 12) return launch_w4_t<Bf16, 128, 2, kW4Ring, 64>(p, causal, stream);   // no wait for the pieces
+    if (force == 14) return launch_w4_t<Bf16, 128, 2, kW4Ring, 128>(p, causal, stream);  // next item's Q rows prefetched
+    if (force == 15) return launch_w4_t<Bf16, 128, 6, kW4Ring, 128>(p, causal, stream);  // the same, prescaled flavour
+    if (force == 13) return launch_w4_t<Bf16, 128, 2, kW4Ring, 80>(p, causal, stream);   // pieces issued, never waited for, no barrier
 #endif
     const bool prescaled = force == 0 ? p.fast_scale != 0 : force == 1;
     if (dtype == SFA_DTYPE_FP16)

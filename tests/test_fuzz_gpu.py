@@ -23,7 +23,7 @@ def sfa():
 def test_fuzz_prefill(sfa, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = ("bf16", "fp16")[seed % 2]
-    D = (128, 64)[int(rng.integers(2))]
+    D = (128, 64, 256)[int(rng.integers(3))]
     Hkv = int(rng.integers(1, 4))
     Hq = Hkv * int(rng.choice([1, 1, 2, 4]))
     B = int(rng.integers(1, 4))

@@ -61,6 +61,8 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
     (1, 1, 1, 1800, 1800, 64),     # 8 q-tiles, ragged last tile
     (2, 4, 2, 1100, 1100, 128),    # several heads per XCD list of the persistent kernel, ragged, GQA
     (1, 10, 10, 700, 700, 128),    # more heads than XCDs: persistent workgroups walk several units
+    (1, 2, 1, 300, 300, 256),      # head_dim 256 (its own kernel, whatever prefill_impl says), GQA, ragged
+    (2, 3, 3, 129, 400, 256),      # Sq < Sk
 ]
 
 
@@ -95,6 +97,8 @@ def select_impl(knobs, impl):
 def serves(impl, D):
     if impl == "auto":
         return True
+    if D == 256:
+        return False                    # one kernel only: covered by "auto"
     return D in (W4_DIMS if impl.endswith("w4") else OLD_DIMS)
 
 
