@@ -72,11 +72,18 @@ def test_config2_headline_shape(sfa):
     B, H, S, D = 16, 32, 4096, 128
     q, k, v, full = _prefill_full_size(sfa, B, H, S, D, True, [(0, 0), (15, 31), (7, 13)], 200)
     # (3) causal prefix: row i depends on keys <= i only, so the first 1024 rows of every head are
-    # bit-identical to the 1024-token problem (same kernel, same tile order)
-    part = sfa.flash_attn_fwd(q[:, :, :1024].contiguous(), k[:, :, :1024].contiguous(), v[:, :, :1024].contiguous(),
-                              causal=True)
-    torch.cuda.synchronize()
+    # bit-identical to the 1024-token problem when the SAME kernel serves it (same tile order per row).  The
+    # library's own choice for the short problem is the 8-wave kernel: equal to a rounding flip.
+    qs, ks, vs = (t[:, :, :1024].contiguous() for t in (q, k, v))
+    part_auto = sfa.flash_attn_fwd(qs, ks, vs, causal=True)
+    sfa.debug_set("prefill_impl", 40)           # the 4-wave kernel, as the full-size launch above
+    try:
+        part = sfa.flash_attn_fwd(qs, ks, vs, causal=True)
+        torch.cuda.synchronize()
+    finally:
+        sfa.debug_set("prefill_impl", -1)
     assert torch.equal(full[:, :, :1024], part)
+    np.testing.assert_allclose(f32(part_auto), f32(part), atol=TOL / 2, rtol=TOL / 2)
 
 
 def test_config4_per_gpu_shard(sfa):
