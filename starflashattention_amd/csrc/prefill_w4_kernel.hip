@@ -640,11 +640,12 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     };
     // DIAG: one workgroup stamps s_memtime at five points of steps 8..15 of its first item into p.lse (as
     // u64[wave][step][8]); the stamp drains lgkmcnt, so read SHARES from it, not absolute speed.
-    auto stamp = [&](int step, int which) {
-        if ((DIAG & 1) && blockIdx.x == 8 && step >= 8 && step < 16 && p.lse) {
+    int item_no = 0;                            // q-tiles this workgroup has finished
+    auto stamp = [&](int step, int which) {     // steps 8..15 of the first q-tile and steps 0..7 of the second
+        if ((DIAG & 1) && blockIdx.x == 8 && p.lse && ((item_no == 0 && step >= 8 && step < 16) || (item_no == 1 && step < 8))) {
             unsigned long long tm;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
-            if (lane == 0) reinterpret_cast<unsigned long long *>(p.lse)[(wave * 8 + (step - 8)) * 8 + which] = tm;
+            if (lane == 0) reinterpret_cast<unsigned long long *>(p.lse)[((item_no * 4 + wave) * 8 + (step & 7)) * 8 + which] = tm;
         }
     };
     // stream prologue: K(0), K(1), V(0) must be visible before the first step; the rest in flight
@@ -693,9 +694,21 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     // loading them at the start of their own item: -1..-2 % causal, +0.5 % full (same-run A/B); off.
     constexpr bool QPRE = (DIAG & 128) != 0;
     if (cc.live && QPRE) load_q(cc.b, cc.h, cc.qt);
+    // DIAG 256: workgroup 8 stamps six points of each of its first 16 q-tiles (kept in scalars, stored behind the
+    // q-tile's epilogue) into p.lse as u64[wave][item][8]: 0 start, 1 Q rows in registers, 2 first half-tile scored
+    // and led in, 3 end of the full steps, 4 end of the tail and idle steps, 5 end of the epilogue; [6] = ntw, [7] = nt
+    unsigned long long its[6] = {0, 0, 0, 0, 0, 0};
+    auto istamp = [&](int which) {
+        if ((DIAG & 256) && blockIdx.x == 8) {
+            unsigned long long tm;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+            its[which] = tm;
+        }
+    };
     while (cc.live) {
         const int qt = cc.qt, nt = cc.nt;
         const int b = cc.b, h = cc.h;
+        istamp(0);
         if (!QPRE) load_q(b, h, qt);
         prescale_q();
         W4Cursor nx;                            // the item after this one (set where its Q rows are requested: exactly
@@ -705,9 +718,12 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         for (int q = 0; q < NQB; ++q)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) asm volatile("s_nop 1" : "+a"(qf[q][ks]));
+        istamp(1);
         const int wq0 = qt * kRows + 64 * wave;                 // this wave's first query row
         int ntw = nt;                                           // tiles this wave computes on (wave-uniform)
-        if (CAUSAL) ntw = (wq0 + 63 + coff >= 0) ? min(nt, (wq0 + 63 + coff) / kKeys + 1) : 0;
+        // (stopping every wave at its own diagonal tile and letting it idle at the barriers, against running all
+        // four to the q-tile's last tile over fully masked scores -- DIAG 512: the same exact-scale, 3 % slower prescaled)
+        if (CAUSAL && !(DIAG & 512)) ntw = (wq0 + 63 + coff >= 0) ? min(nt, (wq0 + 63 + coff) / kKeys + 1) : 0;
         int lim[NQB];                                           // last visible key of this lane's rows
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -772,6 +788,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         }
 
         int t = 0;
+        istamp(2);
         // ---- FULL steps: this wave needs the next tile as well.  A and B are the score registers of the two
         // 32-key halves of a tile; each half-step computes one and consumes the other:
         //   H1(t): S(B_t) = K(t)[32:64] Q^T     || softmax(A_t), O += P(A_t) V(t)[0:32]
@@ -801,6 +818,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             kcur = k1;
             vcur = ring_next(vcur);
         }
+        istamp(3);
         // ---- TAIL step: this wave's last tile (its second half computes no new scores) ----
         if (t < ntw) {
             const int kbase = t * kKeys;
@@ -833,6 +851,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             vcur = ring_next(vcur);
         }
 
+        istamp(4);
         // ---- epilogue: normalise, convert, store O[row][:] ----
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -844,12 +863,21 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             if (qrow < p.Sq) {
                 uint16_t *orow = p.o + b * p.os[0] + h * p.os[1] + (long long)qrow * p.os[2];
                 store_o_row<Tr, D>(orow, acc.o[q], inv, h2);
-                if (p.lse && h2 == 0) {
+                if (!(DIAG & 257) && p.lse && h2 == 0) {
                     const float lse = ltot > 0.f ? (acc.msc[q] + __log2f(ltot)) * kLn2 : ninf();
                     p.lse[((long long)b * p.Hq + h) * p.Sq + qrow] = lse;
                 }
             }
         }
+        istamp(5);
+        if ((DIAG & 256) && blockIdx.x == 8 && item_no < 16 && p.lse && lane == 0) {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.lse) + (wave * 16 + item_no) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dst[i] = its[i];
+            dst[6] = (unsigned long long)ntw;
+            dst[7] = (unsigned long long)nt;
+        }
+        ++item_no;
         cc = nx;
     }
     // drain: DMA pieces issued for stream positions nobody consumes do not exist (the producers stop at the
@@ -895,6 +923,9 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     // force 3 / 4: the other ring depth / the stamping build (bf16, exact) -- A/B and diagnostics only
     if (force == 3) return launch_w4_t<Bf16, 128, 2, 7 - kW4Ring, 0>(p, causal, stream);
     if (force == 4) return launch_w4_t<Bf16, 128, 2, kW4Ring, 1>(p, causal, stream);
+    if (force == 16) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256>(p, causal, stream);     // q-tile level stamps
+    if (force == 17) return launch_w4_t<Bf16, 128, 2, kW4Ring, 512>(p, causal, stream);     // all waves run to the last tile
+    if (force == 18) return launch_w4_t<Bf16, 128, 6, kW4Ring, 512>(p, causal, stream);
 #ifdef SFA_WITH_VARIANTS      // timing-only ablations (results wrong by construction): the A/B library only
     if (force == 5) return launch_w4_t<Bf16, 128, 2, kW4Ring, 2>(p, causal, stream);     // no LDS-DMA
     if (force == 6) return launch_w4_t<Bf16, 128, 2, kW4Ring, 4>(p, causal, stream);     // no softmax stages

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic (prefill_impl 56: the q-tile stamping build of the 4-wave kernel): where the life of a q-tile goes,
+per wave of workgroup 8, over its first 16 q-tiles.  usage: [--noncausal]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import starflashattention_amd as sfa
+sfa.debug_set("prefill_impl", 56)
+B, H, S, D = 16, 32, 4096, 128
+causal = "--noncausal" not in sys.argv
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(1)
+q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).bfloat16() for _ in range(3))
+if "--kvshared" in sys.argv:       # every (batch, head) reads the SAME K/V (stride 0): all re-reads hit L2
+    k, v = k[:1, :1].expand(B, H, S, D), v[:1, :1].expand(B, H, S, D)
+for _ in range(3):
+    out, lse = sfa.flash_attn_fwd(q, k, v, causal=causal, return_lse=True)
+torch.cuda.synchronize()
+st = lse.view(-1)[: 4 * 16 * 8 * 2].view(torch.int64).view(4, 16, 8).cpu().double()
+names = ["Q wait", "first half-tile", "full steps", "tail + idle", "epilogue", "to next start"]
+print("cycles per q-tile, mean over the 16 q-tiles:  " + "  ".join(f"{n:>15s}" for n in names) + "   per full step   ntw / nt (tile 0..3)")
+for w in range(4):
+    s = st[w]
+    d = [(s[:, i + 1] - s[:, i]).mean().item() for i in range(5)]
+    d.append((s[1:, 0] - s[:-1, 5]).mean().item())
+    steps = (s[:, 6] - 1).clamp(min=1)
+    per = ((s[:, 3] - s[:, 2]) / steps).mean().item()
+    print(f"wave {w}:                                       " + "  ".join(f"{x:15.0f}" for x in d) + f"   {per:10.0f}      " +
+          " ".join(f"{int(a)}/{int(b_)}" for a, b_ in zip(s[:4, 6].tolist(), s[:4, 7].tolist())))
+print("wave 3, per q-tile: tiles, cycles per full step, Q wait, epilogue")
+for it in range(16):
+    s = st[3, it]
+    n = max(1.0, s[6].item() - 1)
+    print(f"   q-tile {it:2d}: ntw {int(s[6]):3d}  per step {((s[3] - s[2]) / n).item():7.0f}  Q wait {(s[1] - s[0]).item():6.0f}  "
+          f"epilogue {(s[5] - s[4]).item():6.0f}  whole q-tile {(s[5] - s[0]).item():8.0f}")
+tot = (st[:, -1, 5] - st[:, 0, 0]).mean().item()
+print(f"16 q-tiles: {tot:.0f} cycles per wave")
