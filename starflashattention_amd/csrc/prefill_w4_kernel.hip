@@ -440,7 +440,6 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     constexpr int NJ = D / 64;                  // 128-byte column pieces per row
     using L = Img<D, RING>;
     constexpr int NDMA = 4 * NJ;                // LDS-DMA pieces a wave issues per step (K tile + V tile)
-    constexpr int NQLD = NQB * NKS;             // global loads load_q() issues per lane (all unconditional)
     static_assert(RING == 3 || RING == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -625,13 +624,6 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     // vmcnt(NDMA), as long as that younger step really issued all of its pieces (it does not once the
     // producer has run out of tiles: then drain).  Ops hipcc issues in between (Q loads, O stores) are
     // younger than the pieces waited for, so they only make the wait stricter.
-    // wait_and_sync_q(): the same right behind load_q() -- its NQLD loads are the youngest vector-memory
-    // operations of the wave and must not be waited for (they are wanted a q-tile later)
-    auto wait_and_sync_q = [&]() {
-        if (DIAG & 16) return;
-        if (RING == 3 || thin_tail) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NQLD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NDMA + NQLD) : "memory");
-    };
     auto wait_and_sync = [&]() {
         if (DIAG & 16) return;                  // timing-only ablation: no wait, no barrier
         if (DIAG & 64) { asm volatile("s_barrier" ::: "memory"); return; }     // timing-only ablation: barrier, no wait for the pieces
@@ -690,9 +682,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             }
     };
 
-    // Requesting the NEXT item's Q rows under the current item's last half-step (DIAG 128) measured no better than
-    // loading them at the start of their own item: -1..-2 % causal, +0.5 % full (same-run A/B); off.
-    constexpr bool QPRE = (DIAG & 128) != 0;
+    constexpr bool QPRE = !(DIAG & 128);        // (diagnostic 128: Q rows loaded at the start of their own q-tile)
     if (cc.live && QPRE) load_q(cc.b, cc.h, cc.qt);
     // DIAG 256: workgroup 8 stamps six points of each of its first 16 q-tiles (kept in scalars, stored behind the
     // q-tile's epilogue) into p.lse as u64[wave][item][8]: 0 start, 1 Q rows in registers, 2 first half-tile scored
@@ -711,8 +701,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         istamp(0);
         if (!QPRE) load_q(b, h, qt);
         prescale_q();
-        W4Cursor nx;                            // the item after this one (set where its Q rows are requested: exactly
-                                                // one of the two places below runs per item)
+        W4Cursor nx;                            // the item after this one (set where its Q rows are requested)
         // Q^T sits in the accumulator file (hipcc waits for the loads here); two wait states before the first MFMA
 #pragma unroll
         for (int q = 0; q < NQB; ++q)
@@ -824,25 +813,11 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             const int kbase = t * kKeys;
             hstep<Tr, D, PF, ORD, 1, 0, false, 0>(lds, k_e, v_e, kcur, vcur, kcur, qf, sB, sA, acc, pend, c2,
                                                   mask_bits(kbase + 32), kbase + 32, h2, lim, kpre);
-            nx = cc;                                            // this item's last QK^T MFMA has been issued: request the
-            next_item(nx, false);                               // next item's Q rows under the last half-step, the idle
-            if (nx.live && QPRE) {                              // steps and the epilogue
-                load_q(nx.b, nx.h, nx.qt);
-                wait_and_sync_q();
-            } else {
-                wait_and_sync();
-            }
-            produce_v();
-            produce_k();
+            SFA_W4_SYNC_AND_STAGE();
             hstep_last<Tr, D, ORD, 1>(lds, v_e, vcur, sB, acc, pend, c2);
             kcur = ring_next(kcur);
             vcur = ring_next(vcur);
             ++t;
-        }
-        if (ntw == 0) {                                         // (a wave without any tile of its own in this item)
-            nx = cc;
-            next_item(nx, false);
-            if (nx.live && QPRE) load_q(nx.b, nx.h, nx.qt);
         }
         // ---- idle steps (causal: tiles beyond this wave's diagonal): keep staging for the others ----
         for (; t < nt; ++t) {
@@ -852,6 +827,13 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         }
 
         istamp(4);
+        // The next q-tile's Q rows are requested HERE, behind this wave's last barrier of the q-tile: their HBM
+        // latency (~3.5k cycles, q-tile stamps) then hides under the epilogue (~4k cycles).  Any earlier and the
+        // loads sit in front of the LDS-DMA pieces in the wave's in-order vector-memory queue, so the next
+        // barrier's wait for the pieces waits for Q as well (measured: the whole workgroup then stalls there).
+        nx = cc;
+        next_item(nx, false);
+        if (nx.live && QPRE) load_q(nx.b, nx.h, nx.qt);
         // ---- epilogue: normalise, convert, store O[row][:] ----
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
@@ -924,6 +906,7 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (force == 3) return launch_w4_t<Bf16, 128, 2, 7 - kW4Ring, 0>(p, causal, stream);
     if (force == 4) return launch_w4_t<Bf16, 128, 2, kW4Ring, 1>(p, causal, stream);
     if (force == 16) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256>(p, causal, stream);     // q-tile level stamps
+    if (force == 19) return launch_w4_t<Bf16, 128, 2, kW4Ring, 384>(p, causal, stream);     // q-tile stamps without Q prefetch
     if (force == 17) return launch_w4_t<Bf16, 128, 2, kW4Ring, 512>(p, causal, stream);     // all waves run to the last tile
     if (force == 18) return launch_w4_t<Bf16, 128, 6, kW4Ring, 512>(p, causal, stream);
 #ifdef SFA_WITH_VARIANTS      // timing-only ablations (results wrong by construction): the A/B library only
@@ -935,7 +918,7 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (force == 10) return launch_w4_t<Bf16, 128, 2, 3, 0, 24>(p, causal, stream);      // DMA pieces in the last gaps of H2
     if (force == 11) return launch_w4_t<Bf16, 128, 2, kW4Ring, 32>(p, causal, stream);   // no load instruction, all else kept
     if (force == 12) return launch_w4_t<Bf16, 128, 2, kW4Ring, 64>(p, causal, stream);   // no wait for the pieces
-    if (force == 14) return launch_w4_t<Bf16, 128, 2, kW4Ring, 128>(p, causal, stream);  // next item's Q rows prefetched
+    if (force == 14) return launch_w4_t<Bf16, 128, 2, kW4Ring, 128>(p, causal, stream);  // next q-tile's Q rows NOT prefetched
     if (force == 15) return launch_w4_t<Bf16, 128, 6, kW4Ring, 128>(p, causal, stream);  // the same, prescaled flavour
     if (force == 13) return launch_w4_t<Bf16, 128, 2, kW4Ring, 80>(p, causal, stream);   // pieces issued, never waited for, no barrier
 #endif

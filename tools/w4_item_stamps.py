@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
-sfa.debug_set("prefill_impl", 56)
+sfa.debug_set("prefill_impl", 59 if "--qpre" in sys.argv else 56)
 B, H, S, D = 16, 32, 4096, 128
 causal = "--noncausal" not in sys.argv
 dev = torch.device("cuda:0")
