@@ -23,7 +23,7 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB_NAME = "libStarFlashAttention.so"
 ARCH = "gfx950"
 
-EXTRA_FLAGS = {}      # per-source extra hipcc flags (none needed at present)
+EXTRA_FLAGS = {}      # per-source extra hipcc flags
 
 KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_w4_kernel.hip", "prefill_d256_kernel.hip",
                   "prefill_kernel.hip", "prefill_kernel_bm128.hip", "prefill_dispatch.hip",

@@ -53,7 +53,7 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     if (which == 0 || (which >= 30 && which <= 32))
         return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d needs the A/B build of the library (build_lib(variants=True))", which);
 #endif
-    if (which >= 40 && which <= 59) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
+    if (which >= 40 && which <= 79) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
     if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);

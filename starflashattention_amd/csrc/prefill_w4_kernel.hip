@@ -467,7 +467,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             const bool exists = c.sub == 0 || (CAUSAL && heavy != c.i);
             if (exists) {
                 if (c.sub == 0 || !CAUSAL) { c.b = bh / p.Hq; c.h = bh - c.b * p.Hq; }
-                c.qt = c.sub == 0 ? heavy : c.i;
+                c.qt = ((c.sub == 0) != (CAUSAL && (DIAG & 4096) != 0)) ? heavy : c.i;    // (diagnostic 4096: the light q-tile of a pair first)
                 c.nt = item_tiles(c.qt);
                 c.t = 0;
                 if (!skip_empty || c.nt > 0) { c.live = true; return; }
@@ -531,7 +531,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         u32x4s srd;
         srd[0] = d.lo;
         srd[1] = d.hi & 0xffffu;
-        srd[2] = live ? (unsigned)max(d.left, 0) : 0u;
+        srd[2] = (live && !(DIAG & 1024)) ? (unsigned)max(d.left, 0) : 0u;     // (diagnostic 1024: every piece out of bounds -- issued, zero-filled, nothing fetched)
         srd[3] = 0x00020000u;
         return srd;
     };
@@ -686,13 +686,16 @@ prefill_w4_kernel(const PrefillKernelParams p) {
     if (cc.live && QPRE) load_q(cc.b, cc.h, cc.qt);
     // DIAG 256: workgroup 8 stamps six points of each of its first 16 q-tiles (kept in scalars, stored behind the
     // q-tile's epilogue) into p.lse as u64[wave][item][8]: 0 start, 1 Q rows in registers, 2 first half-tile scored
-    // and led in, 3 end of the full steps, 4 end of the tail and idle steps, 5 end of the epilogue; [6] = ntw, [7] = nt
-    unsigned long long its[6] = {0, 0, 0, 0, 0, 0};
+    // and led in, 3 end of the full steps, 4 end of the tail and idle steps, 5 end of the epilogue; [6] = ntw | nt << 32,
+    // [7] = the q-tile in s_memrealtime ticks (100 MHz; cycles / ticks = the shader clock the q-tile ran at)
+    unsigned long long its[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0, rt1 = 0;
     auto istamp = [&](int which) {
         if ((DIAG & 256) && blockIdx.x == 8) {
-            unsigned long long tm;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+            unsigned long long tm, rt;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(rt) :: "memory");
             its[which] = tm;
+            if (which == 0) rt0 = rt;
+            if (which == 5) rt1 = rt;
         }
     };
     while (cc.live) {
@@ -856,8 +859,8 @@ prefill_w4_kernel(const PrefillKernelParams p) {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.lse) + (wave * 16 + item_no) * 8;
 #pragma unroll
             for (int i = 0; i < 6; ++i) dst[i] = its[i];
-            dst[6] = (unsigned long long)ntw;
-            dst[7] = (unsigned long long)nt;
+            dst[6] = (unsigned long long)ntw | ((unsigned long long)nt << 32);
+            dst[7] = rt1 - rt0;
         }
         ++item_no;
         cc = nx;
@@ -909,7 +912,8 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (force == 19) return launch_w4_t<Bf16, 128, 2, kW4Ring, 384>(p, causal, stream);     // q-tile stamps without Q prefetch
     if (force == 17) return launch_w4_t<Bf16, 128, 2, kW4Ring, 512>(p, causal, stream);     // all waves run to the last tile
     if (force == 18) return launch_w4_t<Bf16, 128, 6, kW4Ring, 512>(p, causal, stream);
-#ifdef SFA_WITH_VARIANTS      // timing-only ablations (results wrong by construction): the A/B library only
+#ifdef SFA_WITH_VARIANTS      // A/B orderings and timing-only ablations (results of the latter wrong by construction): the A/B library only
+    if (force == 30) return launch_w4_t<Bf16, 128, 2, kW4Ring, 4096>(p, causal, stream); // the light q-tile of a causal pair first (correct results)
     if (force == 5) return launch_w4_t<Bf16, 128, 2, kW4Ring, 2>(p, causal, stream);     // no LDS-DMA
     if (force == 6) return launch_w4_t<Bf16, 128, 2, kW4Ring, 4>(p, causal, stream);     // no softmax stages
     if (force == 7) return launch_w4_t<Bf16, 128, 2, kW4Ring, 8>(p, causal, stream);     // no LDS fragment reads
@@ -921,6 +925,16 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (force == 14) return launch_w4_t<Bf16, 128, 2, kW4Ring, 128>(p, causal, stream);  // next q-tile's Q rows NOT prefetched
     if (force == 15) return launch_w4_t<Bf16, 128, 6, kW4Ring, 128>(p, causal, stream);  // the same, prescaled flavour
     if (force == 13) return launch_w4_t<Bf16, 128, 2, kW4Ring, 80>(p, causal, stream);   // pieces issued, never waited for, no barrier
+    if (force == 20) return launch_w4_t<Bf16, 128, 2, kW4Ring, 1024>(p, causal, stream); // pieces issued with empty descriptors: no memory traffic
+    if (force == 21) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 1024>(p, causal, stream);  // q-tile stamps (cycles AND clock) of the ablations:
+    if (force == 22) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 2>(p, causal, stream);     //   a shorter time can be a faster clock, not
+    if (force == 23) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 4>(p, causal, stream);     //   fewer cycles (zeros in LDS draw less power)
+    if (force == 24) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 30>(p, causal, stream);
+    if (force == 25) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 32>(p, causal, stream);
+    if (force == 26) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 16>(p, causal, stream);
+    if (force == 27) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 64>(p, causal, stream);
+    if (force == 28) return launch_w4_t<Bf16, 128, 2, kW4Ring, 256 + 8>(p, causal, stream);
+    if (force == 29) return launch_w4_t<Bf16, 128, 6, kW4Ring, 256>(p, causal, stream);         // prescaled flavour, stamped
 #endif
     const bool prescaled = force == 0 ? p.fast_scale != 0 : force == 1;
     if (dtype == SFA_DTYPE_FP16)

@@ -6,6 +6,8 @@ import torch
 import starflashattention_amd as sfa
 sfa.debug_set("prefill_impl", int(os.environ.get("IMPL", "-1")))
 B, H, S, D = 16, 32, 4096, 128
+if os.environ.get("SHAPE"):            # SHAPE=B,H,S
+    B, H, S = (int(x) for x in os.environ["SHAPE"].split(","))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).bfloat16() for _ in range(3))
