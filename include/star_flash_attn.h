@@ -137,8 +137,7 @@ typedef struct sfa_decode_args {
     int block_table_stride;         /* entries per sequence, >= ceil(memory_max_len / page_size) */
     int num_pages;                  /* pages in each pool (bounds the table entries)     */
     /* -- grouped queries (no counterpart in the reference; 0 = num_heads) -- */
-    int num_heads_kv;               /* kv heads; num_heads / num_heads_kv in {1, 2, 4, 8} (16 with head_dim
-                                       128).  With
+    int num_heads_kv;               /* kv heads; num_heads / num_heads_kv in {1, 2, 4, 8, 16}.  With
                                        num_heads_kv != num_heads: qkv is [batch, num_heads +
                                        2*num_heads_kv, head_dim] (q heads, k heads, v heads; default
                                        stride (num_heads + 2*num_heads_kv)*head_dim), k_bias / v_bias

@@ -158,8 +158,8 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     const int hkv = a->num_heads_kv > 0 ? a->num_heads_kv : a->num_heads;
     const int group = hkv > 0 ? a->num_heads / hkv : 0;
     if (a->num_heads_kv < 0 || group * hkv != a->num_heads ||
-        (group != 1 && group != 2 && group != 4 && group != 8 && !(group == 16 && a->head_dim == 128)))
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_heads=%d / num_heads_kv=%d must be 1, 2, 4 or 8 (16 with head_dim 128)",
+        (group != 1 && group != 2 && group != 4 && group != 8 && group != 16))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_decode: num_heads=%d / num_heads_kv=%d must be 1, 2, 4, 8 or 16",
                     a->num_heads, a->num_heads_kv);
     const long long hd = (long long)hkv * a->head_dim;          // elements per cache row
     const long long row = (long long)(a->num_heads + 2 * hkv) * a->head_dim;    // packed q,k,v of one token

@@ -306,11 +306,14 @@ int launch_t(const DecodeKernelParams &p, hipStream_t stream) {
 
 // the attention kernel only; launch_decode (decode_kernel.hip) adds the split combine
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
-    // 8 query heads per kv head make this kernel VALU-bound (4.1 TB/s): the matrix-core form takes over
-    // (head_dim 128; sfa_debug_set("decode_gqa_mfma", 0) keeps the VALU kernel for A/B)
-    if (head_dim == 128 && (p.H == 16 * p.Hkv || p.H == 8 * p.Hkv || p.H == 4 * p.Hkv) && (dtype == SFA_DTYPE_FP16 || dtype == SFA_DTYPE_BF16)) {
-        if (g_knobs.decode_gqa_mfma.load(std::memory_order_relaxed) != 0 || p.H == 16 * p.Hkv)
-            return launch_decode_gqa_mfma(p, dtype, stream);
+    // 8 query heads per kv head make this kernel VALU-bound (4.1 TB/s at head_dim 128): the matrix-core form takes
+    // over -- for groups of 16 always, for 8 at any head_dim, for 4 at head_dim 128 (measured there); 
+    // sfa_debug_set("decode_gqa_mfma", 0) keeps the VALU kernel for A/B, 1 forces the matrix-core kernel for groups of 4
+    if ((head_dim == 128 || head_dim == 64 || head_dim == 256) && (p.H == 16 * p.Hkv || p.H == 8 * p.Hkv || p.H == 4 * p.Hkv) &&
+        (dtype == SFA_DTYPE_FP16 || dtype == SFA_DTYPE_BF16)) {
+        const int knob = g_knobs.decode_gqa_mfma.load(std::memory_order_relaxed);
+        const bool by_default = head_dim == 128 || p.H >= 8 * p.Hkv;
+        if (p.H == 16 * p.Hkv || (knob < 0 ? by_default : knob != 0)) return launch_decode_gqa_mfma(p, dtype, head_dim, stream);
     }
     if (dtype == SFA_DTYPE_FP16) {
         if (head_dim == 128) return launch_t<Fp16, 128>(p, stream);

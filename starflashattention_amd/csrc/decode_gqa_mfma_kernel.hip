@@ -32,10 +32,13 @@ using prefill::lds_i16x4;
 
 constexpr int kTile = 32;                       // keys per tile
 
-template <class Tr, int G, bool NT, bool KLDS, bool PAGED = false>
+template <class Tr, int D, int G, bool NT, bool KLDS, bool PAGED = false>
 __global__ void __launch_bounds__(kDecodeWaves * 64)
 decode_gqa_mfma_kernel(const DecodeKernelParams p) {
-    constexpr int D = 128, W = kDecodeWaves;
+    constexpr int W = kDecodeWaves;
+    constexpr int LPR = D / 8;                  // lanes (16-byte chunks) per cache row
+    constexpr int RPL = 64 / LPR;               // rows one load instruction of a wave covers
+    constexpr int NLD = kTile / RPL;            // row-major loads per 32-row tile (= 2 NKS)
     constexpr int NKS = D / 32;                 // k-steps of a QK^T accumulator
     constexpr int NDT = D / 16;                 // 16-wide d tiles of O^T
     constexpr int VS = 2 * D + 32;              // LDS row stride of the V tile (conflict-free transposed reads)
@@ -49,7 +52,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     const int hk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, g = lane >> 4;     // MFMA lane coordinates
-    const int sub = lane & 15;                  // prologue / epilogue: which 8 dims (same 16-lane split)
+    const int sub = lane % LPR, grp = lane / LPR;   // row-major coordinates: which 8 dims, which row of a load (prologue: which head)
     const int S = p.num_splits;
     const int Hq = p.H, Hkv = p.Hkv;
 
@@ -98,7 +101,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     };
     uint16_t *const qs = reinterpret_cast<uint16_t *>(vbuf);            // [16][D] query rows (rows >= G zero)
     uint16_t *const kn = qs + 16 * D;                                   // [D] the new token's key
-    for (int q = g; q < 16; q += 4) {
+    for (int q = grp; q < 16; q += RPL) {
         uint4 pk = make_uint4(0, 0, 0, 0);
         if (q < G) {
             float x[8];
@@ -134,7 +137,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         }
         rope(xk);
         kpk = pack8<Tr>(xk);
-        if (g == 0) *reinterpret_cast<uint4 *>(kn + sub * 8) = kpk;
+        if (grp == 0) *reinterpret_cast<uint4 *>(kn + sub * 8) = kpk;
     }
     // Q^T fragments (B operand): lane holds Q[q = c][32 ks + 8 g .. +8]
     Vec qf[NKS];
@@ -187,7 +190,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         return po[half] + (long long)(row & pmask) * rs;
     };
     const uint16_t *const kb = p.k_cache + head_base + 8 * g;          // + row * rs + 32 ks: operand layout
-    const uint16_t *const vb = p.v_cache + head_base + 8 * (lane & 15);    // + row * rs: row-major chunks
+    const uint16_t *const vb = p.v_cache + head_base + 8 * sub;            // + row * rs: row-major chunks
 
     f32x4 o[NDT];
 #pragma unroll
@@ -203,26 +206,26 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
             const int row = min(t + 16 * kt + c, w1 - 1);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (KLDS) {     // row-major like V (256-B rows): rows 16 kt + 4 ks + (lane >> 4), chunk lane & 15
-                    const int r2 = min(t + 16 * kt + 4 * ks + (lane >> 4), w1 - 1);
-                    kk[kt][ks] = ld16<NT>(p.k_cache + head_base + row_off(r2, kt) + 8 * (lane & 15));
+                if (KLDS) {     // row-major like V: load j = kt NKS + ks covers rows RPL j + grp, chunk sub
+                    const int r2 = min(t + RPL * (kt * NKS + ks) + grp, w1 - 1);
+                    kk[kt][ks] = ld16<NT>(p.k_cache + head_base + row_off(r2, kt) + 8 * sub);
                 } else {        // directly in operand layout: 64-B pieces of 16 rows
                     kk[kt][ks] = ld16<NT>(kb + (long long)row * rs + 32 * ks);
                 }
             }
         }
     };
-    auto load_v = [&](uint4 (&vv)[8], int t) {          // lane: rows (lane >> 4) + 4 i, chunk lane & 15
+    auto load_v = [&](uint4 (&vv)[NLD], int t) {        // lane: rows grp + RPL i, chunk sub
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = min(t + (lane >> 4) + 4 * i, w1 - 1);
-            vv[i] = ld16<NT>(vb + row_off(row, i >> 2));
+        for (int i = 0; i < NLD; ++i) {
+            const int row = min(t + grp + RPL * i, w1 - 1);
+            vv[i] = ld16<NT>(vb + row_off(row, (RPL * i) >> 4));
         }
     };
-    auto store_v = [&](const uint4 (&vv)[8], char *buf) {
+    auto store_v = [&](const uint4 (&vv)[NLD], char *buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<uint4 *>(buf + VS * ((lane >> 4) + 4 * i) + 16 * (lane & 15)) = vv[i];
+        for (int i = 0; i < NLD; ++i)
+            *reinterpret_cast<uint4 *>(buf + VS * (grp + RPL * i) + 16 * sub) = vv[i];
     };
     // KLDS: the K tile came in row-major; lay it out as MFMA operands through the wave's LDS K tile
     auto to_operand = [&](uint4 (&kk)[2][NKS]) {
@@ -231,7 +234,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
-                *reinterpret_cast<uint4 *>(kbuf + KS * (16 * kt + 4 * ks + (lane >> 4)) + 16 * (lane & 15)) = kk[kt][ks];
+                *reinterpret_cast<uint4 *>(kbuf + KS * (RPL * (kt * NKS + ks) + grp) + 16 * sub) = kk[kt][ks];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -293,7 +296,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     if (w0 < w1) {
         // tile t+1 is in flight into registers while tile t is computed; the LDS tiles are single: a wave's
         // LDS operations execute in order, so storing tile t+1 cannot overtake the reads of tile t
-        uint4 ka[2][NKS], kb2[2][NKS], vr[8];
+        uint4 ka[2][NKS], kb2[2][NKS], vr[NLD];
         load_k(ka, w0);
         load_v(vr, w0);
         for (int t = w0; t < w1; t += 2 * kTile) {
@@ -314,9 +317,9 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     // ---- the new token (position `pos`): last split, wave 0 -- a tile with one real key ----
     if (split == S - 1 && wave == 0) {
         {   // every row of the V tile = v_new (rows 1.. get weight 0, but 0 * stale LDS bits could be NaN)
-            uint4 vv[8];
+            uint4 vv[NLD];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) vv[i] = vpk;
+            for (int i = 0; i < NLD; ++i) vv[i] = vpk;
             store_v(vv, vbuf);
         }
         uint4 kk[2][NKS];
@@ -326,7 +329,7 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
             kk[1][ks] = make_uint4(0, 0, 0, 0);
         }
         tile(kk, vbuf, 1);
-        if (g == 0) {                           // append: 16 lanes x 16 B = one row each
+        if (grp == 0) {                         // append: LPR lanes x 16 B = one row each
             long long roff = head_base + (long long)pos * rs + sub * 8;
             if (PAGED) roff = head_base + page_of(pos >> p.page_shift) + (long long)(pos & pmask) * rs + sub * 8;
             *reinterpret_cast<uint4 *>(p.k_cache + roff) = kpk;
@@ -347,8 +350,8 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
         if (g == 0) { red[(wave * G + c) * (D + 2) + D] = m; red[(wave * G + c) * (D + 2) + D + 1] = ltot; }
     }
     __syncthreads();
-    if (tid < 16 * G) {
-        const int q = tid / 16, sb = tid % 16;
+    for (int idx = tid; idx < LPR * G; idx += W * 64) {
+        const int q = idx / LPR, sb = idx % LPR;
         Stream tot;
         tot.init();
 #pragma unroll
@@ -375,40 +378,49 @@ decode_gqa_mfma_kernel(const DecodeKernelParams p) {
     }
 }
 
-template <class Tr, int G, bool NT, bool KLDS, bool PAGED = false>
+template <class Tr, int D, int G, bool NT, bool KLDS, bool PAGED = false>
 int launch_k(const DecodeKernelParams &p, hipStream_t stream) {
     dim3 grid(p.Hkv, p.num_splits, p.B), block(kDecodeWaves * 64);
-    constexpr int lds = kDecodeWaves * kTile * ((2 * 128 + 32) + (2 * 128 + 16));       // 71,680 B
-    static_assert(lds >= kDecodeWaves * G * (128 + 2) * 4, "merge area fits");
+    constexpr int lds = kDecodeWaves * kTile * ((2 * D + 32) + (2 * D + 16));       // 71,680 B at head_dim 128
+    static_assert(lds >= kDecodeWaves * G * (D + 2) * 4, "merge area fits");
+    static_assert(kTile * (2 * D + 32) >= 17 * D * 2, "the query rows and the new key fit the V tile they are re-laid out in");
     static DynLdsAttr attr;
-    if (const int rc = attr.ensure(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>), lds,
+    if (const int rc = attr.ensure(reinterpret_cast<const void *>(&decode_gqa_mfma_kernel<Tr, D, G, NT, KLDS, PAGED>), lds,
                                    "decode_gqa_mfma_kernel"))
         return rc;
-    hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, G, NT, KLDS, PAGED>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((decode_gqa_mfma_kernel<Tr, D, G, NT, KLDS, PAGED>), grid, block, lds, stream, p);
     return check_launch("decode_gqa_mfma_kernel");
 }
 
-template <class Tr, int G>
+template <class Tr, int D, int G>
 int launch_g(const DecodeKernelParams &p, hipStream_t stream) {
-    bool nt = 4ll * p.B * p.L * p.M * p.Hkv * 128 > (256ll << 20);      // see decode_kernel.hip
+    bool nt = 4ll * p.B * p.L * p.M * p.Hkv * D > (256ll << 20);        // see decode_kernel.hip
     if (const int k = g_knobs.decode_nt.load(std::memory_order_relaxed); k >= 0) nt = k != 0;      // tests, A/B
     // Reference layout: a K row of this head is a 256-B segment H*D*2 bytes from the next, and fetching it
     // as 64-B operand pieces costs 8 % (5.96 vs 6.44 TB/s): load row-major, re-lay out through LDS.
     // Head-major caches are contiguous, the operand-layout loads go straight to registers (6.7 TB/s).
     if (p.block_table)
-        return nt ? launch_k<Tr, G, true, true, true>(p, stream) : launch_k<Tr, G, false, true, true>(p, stream);
-    const bool klds = p.kv_row_stride != 128;
-    if (klds) return nt ? launch_k<Tr, G, true, true>(p, stream) : launch_k<Tr, G, false, true>(p, stream);
-    return nt ? launch_k<Tr, G, true, false>(p, stream) : launch_k<Tr, G, false, false>(p, stream);
+        return nt ? launch_k<Tr, D, G, true, true, true>(p, stream) : launch_k<Tr, D, G, false, true, true>(p, stream);
+    const bool klds = p.kv_row_stride != D;
+    if (klds) return nt ? launch_k<Tr, D, G, true, true>(p, stream) : launch_k<Tr, D, G, false, true>(p, stream);
+    return nt ? launch_k<Tr, D, G, true, false>(p, stream) : launch_k<Tr, D, G, false, false>(p, stream);
+}
+
+template <class Tr, int D>
+int launch_d(const DecodeKernelParams &p, hipStream_t stream) {
+    if (p.H == 16 * p.Hkv) return launch_g<Tr, D, 16>(p, stream);
+    if (p.H == 4 * p.Hkv) return launch_g<Tr, D, 4>(p, stream);
+    return launch_g<Tr, D, 8>(p, stream);
 }
 
 }  // namespace
 
-// head_dim 128, any cache layout, 4, 8 or 16 query heads per kv head
-int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream) {
-    if (p.H == 16 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 16>(p, stream) : launch_g<Bf16, 16>(p, stream);
-    if (p.H == 4 * p.Hkv) return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 4>(p, stream) : launch_g<Bf16, 4>(p, stream);
-    return dtype == SFA_DTYPE_FP16 ? launch_g<Fp16, 8>(p, stream) : launch_g<Bf16, 8>(p, stream);
+// head_dim 64 / 128 / 256, any cache layout, 4, 8 or 16 query heads per kv head
+int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream) {
+    const bool h = dtype == SFA_DTYPE_FP16;
+    if (head_dim == 64) return h ? launch_d<Fp16, 64>(p, stream) : launch_d<Bf16, 64>(p, stream);
+    if (head_dim == 256) return h ? launch_d<Fp16, 256>(p, stream) : launch_d<Bf16, 256>(p, stream);
+    return h ? launch_d<Fp16, 128>(p, stream) : launch_d<Bf16, 128>(p, stream);
 }
 
 }  // namespace sfa

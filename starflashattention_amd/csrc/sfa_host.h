@@ -53,7 +53,7 @@ struct PrefillKernelParams {
 
 int launch_decode(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
 int launch_decode_gqa(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
-int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, hipStream_t stream);
+int launch_decode_gqa_mfma(const DecodeKernelParams &p, int dtype, int head_dim, hipStream_t stream);
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream);
 int launch_prefill_no_keys(const PrefillKernelParams &p, int head_dim, hipStream_t stream);
 int launch_rotary_table(void *cos_t, void *sin_t, int max_seq_len, int rot_dim, int dtype, hipStream_t stream);

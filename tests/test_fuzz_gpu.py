@@ -93,15 +93,14 @@ def test_fuzz_decode(sfa, seed):
                                err_msg=f"B={B} H={H} D={D} L={L} M={M} rot={rot} splits={splits} {layout} lens={lens}")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_fuzz_decode_grouped(sfa, seed):
     """Grouped queries (VALU and matrix-core kernels, all layouts) against the oracle on the expanded problem."""
     rng = np.random.default_rng(3000 + seed)
     dtype = ("fp16", "bf16")[seed % 2]
     D = int(rng.choice([64, 128, 128, 128, 256]))
     G = int(rng.choice([2, 4, 8, 16]))
-    if G == 16:
-        D = 128                                 # groups of 16 exist for head_dim 128 only (matrix-core kernel)
+    force = int(rng.choice([-1, -1, 0, 1]))     # -1: the library's choice of kernel; 0 / 1: VALU / matrix-core where both exist
     Hkv = int(rng.integers(1, 4))
     H = Hkv * G
     B = int(rng.integers(1, 4))
@@ -135,8 +134,12 @@ def test_fuzz_decode_grouped(sfa, seed):
         kw.update(kv_layout="paged", block_table=table)
     o = torch.empty((B, H, D), dtype=TDT[dtype], device=dev)
     z = torch.zeros(0, dtype=TDT[dtype], device=dev)
-    sfa.flash_decode(t(qkv), z, z, z, k_t, v_t, torch.tensor(lens, dtype=torch.int32, device=dev), o, B, M, H, D, rot,
-                     M, 1, 0, **kw)
-    sfa.check_decode_status()
+    sfa.debug_set("decode_gqa_mfma", force)
+    try:
+        sfa.flash_decode(t(qkv), z, z, z, k_t, v_t, torch.tensor(lens, dtype=torch.int32, device=dev), o, B, M, H, D, rot,
+                         M, 1, 0, **kw)
+        sfa.check_decode_status()
+    finally:
+        sfa.debug_set("decode_gqa_mfma", -1)
     np.testing.assert_allclose(o.float().cpu().numpy(), ref["o"], atol=TOL[dtype], rtol=TOL[dtype],
-                               err_msg=f"B={B} H={H} Hkv={Hkv} D={D} M={M} rot={rot} splits={splits} {layout} lens={lens}")
+                               err_msg=f"B={B} H={H} Hkv={Hkv} D={D} M={M} rot={rot} splits={splits} {layout} lens={lens} force={force}")

@@ -9,7 +9,9 @@ import starflashattention_amd as sfa
 
 variants = [int(a) for a in sys.argv[1:]] or [0, 1]
 layouts = os.environ.get("LAYOUTS", "blmhd").split(",")
-B, H, Sk, D = 256, 32, 8192, 128
+B, H, Sk, D = 256, 32, 8192, int(os.environ.get("HD", "128"))
+if os.environ.get("MFMA"):                   # grouped queries: 0 forces the VALU kernel, 1 the matrix-core kernel
+    sfa.debug_set("decode_gqa_mfma", int(os.environ["MFMA"]))
 GQA = int(os.environ.get("GQA", "1"))       # query heads per kv head (extension): Hq = 32, Hkv = 32 / GQA
 HQ, H = H, H // GQA                         # from here on H = kv heads
 dev = torch.device("cuda:0")
@@ -50,4 +52,4 @@ for rep in range(2):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 6
-            print(f"GQA {GQA} layout {layout} nt {nt}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s", flush=True)
+            print(f"D {D} GQA {GQA} mfma {os.environ.get('MFMA', 'auto')} layout {layout} nt {nt}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s", flush=True)
