@@ -62,7 +62,8 @@ template <int D, int RING = 3> struct Img {
     static constexpr int TILE = 8 * RG;             // 64 rows
     static constexpr int K_BASE = 0;
     static constexpr int V_BASE = RING * TILE;
-    static constexpr int TOTAL = 2 * RING * TILE;
+    static constexpr int Q_BASE = 2 * RING * TILE;  // the Q rows of the next q-tile, one 64-row image per wave (wave-private)
+    static constexpr int TOTAL = Q_BASE + 4 * TILE;
 };
 
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
@@ -655,17 +656,40 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         produce_k();                                                                                \
     } while (0)
 
+    // Q rows reach the accumulator file through LDS: a lane pair owns ONE query row, so loading the operand layout
+    // straight from memory touches 32 rows with 32 B each per instruction and every cache line eight times -- the 16
+    // loads of a wave took 1-2k cycles to ISSUE and the address path was busy with them for most of the ~8k-cycle
+    // epilogue they were meant to hide under (q-tile stamps).  As LDS-DMA pieces in the K image (8 rows x 128 B per
+    // piece, a quarter of the line visits) into a wave-private 64-row image, read back like K fragments.
+    // request_q: 16 pieces, issued where load_q() was; fetch_q: when the rows are needed.  Rows past Sq read as zeros.
     Vec qf[NQB][NKS];
+    const unsigned q_rowb = (unsigned)(2 * p.qs[2]);
+    const unsigned qvoff0 = (unsigned)r8 * q_rowb + 64u * dsub + 16u * (dslot ^ (r8 >> 2));
+    const unsigned qvoff1 = (unsigned)(r8 + 8) * q_rowb + 64u * dsub + 16u * (dslot ^ (2 + (r8 >> 2)));
     auto load_q = [&](int b, int h, int qt) {
+        const int row0 = qt * kRows + 64 * wave;
+        const unsigned long long base = (unsigned long long)(uintptr_t)(p.q + b * p.qs[0] + h * p.qs[1]) + (unsigned long long)row0 * q_rowb;
+        u32x4s srd;
+        srd[0] = (unsigned)base;
+        srd[1] = (unsigned)(base >> 32) & 0xffffu;
+        srd[2] = row0 < p.Sq ? (unsigned)(p.Sq - 1 - row0) * q_rowb + 2u * D : 0u;
+        srd[3] = 0x00020000u;
+        const unsigned dst = lds0 + L::Q_BASE + wave * L::TILE;
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            const int qrow = qt * kRows + 64 * wave + 32 * q + l31;
-            const uint16_t *qp = p.q + b * p.qs[0] + h * p.qs[1] + (long long)min(qrow, p.Sq - 1) * p.qs[2] + 8 * h2;
+        for (int rg = 0; rg < 8; ++rg)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                qf[q][ks] = bitcast<Vec>(*reinterpret_cast<const uint4 *>(qp + 16 * ks));
-            }
-        }
+            for (int j = 0; j < NJ; ++j)
+                dma_piece(dst + rg * L::RG + 1024 * j, (rg & 1) ? qvoff1 : qvoff0, srd, 128u * j + 16u * (rg >> 1) * q_rowb);
+    };
+    const unsigned q_e = L::Q_BASE + L::RG * (l31 >> 3) + 64 * (l31 & 7) + 16 * (h2 ^ ((l31 >> 2) & 3));
+    auto fetch_q = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pieces (and whatever this wave stored since)
+        const lds_char *const qe = lds + (q_e + wave * L::TILE), *const qo = lds + ((q_e ^ 32) + wave * L::TILE);
+#pragma unroll
+        for (int q = 0; q < NQB; ++q)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                qf[q][ks] = bitcast<Vec>(lds_read16(((ks & 1) ? qo : qe) + 4 * L::RG * q + 512 * (ks >> 1)));
     };
     // prescaled flavour: fold scale * log2(e) into Q once per q-tile, when the rows are first needed (not where
     // they are requested: that would wait for the loads on the spot)
@@ -703,9 +727,10 @@ prefill_w4_kernel(const PrefillKernelParams p) {
         const int b = cc.b, h = cc.h;
         istamp(0);
         if (!QPRE) load_q(b, h, qt);
+        fetch_q();
         prescale_q();
         W4Cursor nx;                            // the item after this one (set where its Q rows are requested)
-        // Q^T sits in the accumulator file (hipcc waits for the loads here); two wait states before the first MFMA
+        // Q^T sits in the accumulator file (written from the LDS image just now); two wait states before the first MFMA
 #pragma unroll
         for (int q = 0; q < NQB; ++q)
 #pragma unroll
@@ -903,8 +928,10 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
         return fail(SFA_ERR_UNSUPPORTED_HEAD_DIM, "sfa_prefill_fwd: the 4-wave kernel serves head_dim 128 (got %d)", head_dim);
     // the K/V rows of one head are addressed through a 32-bit buffer descriptor
     const long long k_ext = (long long)(p.Sk - 1) * 2 * p.ks[2] + 2 * head_dim, v_ext = (long long)(p.Sk - 1) * 2 * p.vs[2] + 2 * head_dim;
-    if (k_ext >= (1ll << 31) || v_ext >= (1ll << 31) || p.ks[2] * 2 >= (1ll << 24) || p.vs[2] * 2 >= (1ll << 24))
-        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: one head's K/V rows span more than 2 GiB");
+    const long long q_ext = (long long)(p.Sq - 1) * 2 * p.qs[2] + 2 * head_dim;
+    if (k_ext >= (1ll << 31) || v_ext >= (1ll << 31) || q_ext >= (1ll << 31) || p.ks[2] * 2 >= (1ll << 24) || p.vs[2] * 2 >= (1ll << 24) ||
+        p.qs[2] * 2 >= (1ll << 24))
+        return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: one head's Q/K/V rows span more than 2 GiB");
     // force 3 / 4: the other ring depth / the stamping build (bf16, exact) -- A/B and diagnostics only
     if (force == 3) return launch_w4_t<Bf16, 128, 2, 7 - kW4Ring, 0>(p, causal, stream);
     if (force == 4) return launch_w4_t<Bf16, 128, 2, kW4Ring, 1>(p, causal, stream);
