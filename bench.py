@@ -140,6 +140,31 @@ def bench_config5_shard(torch, sfa, steps):
             "ms_per_step": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
 
 
+def bench_gemm_calibration(torch):
+    """What the matrix cores of THIS device sustain on a plain library GEMM (hipBLASLt through torch.matmul) with the
+    operand data of the attention benchmark (randn, bf16): the device clocks down under dense MFMA work on real data
+    (DESIGN.md 5.2 "Power"), so this -- not the nominal 2.5 PFLOP/s `roofline.peak` must use -- is the practical
+    ceiling next to which the attention figure reads.  A yardstick only: nothing of the product runs through it."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    M = 8192
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn((M, M), generator=g, device=dev).bfloat16()
+    bt = torch.randn((M, M), generator=g, device=dev).bfloat16().t()       # "NT": the library's fastest layout here
+    for _ in range(5):
+        torch.matmul(a, bt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        torch.matmul(a, bt)
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 2.0 * M ** 3 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12
+    return {"workload": "torch.matmul bf16 8192^3, randn operands, B transposed (hipBLASLt)", "tflops": round(tf, 1),
+            "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+            "note": "library GEMM on the same device and data distribution: the power-capped MFMA rate, not a target"}
+
+
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: start N fresh ranks (torch.distributed.run) and relay their output.
     Nothing in THIS process has touched a GPU yet (torch is not even imported), and it is never replaced by
@@ -279,6 +304,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 rec["config5_shard"] = {"error": repr(e)[:200]}
+            try:
+                rec["gemm_calibration"] = bench_gemm_calibration(torch)
+                torch.cuda.empty_cache()
+            except Exception as e:
+                rec["gemm_calibration"] = {"error": repr(e)[:200]}
             try:
                 rec["decode_roofline"] = bench_decode(torch, sfa, min(50, max(3, args.steps // 2)), 3)
             except Exception as e:                      # the headline number must still print
