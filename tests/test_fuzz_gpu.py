@@ -19,7 +19,7 @@ def sfa():
     return m
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_fuzz_prefill(sfa, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = ("bf16", "fp16")[seed % 2]
@@ -42,11 +42,17 @@ def test_fuzz_prefill(sfa, seed):
     def lay(x):
         x = t(x)
         return x.transpose(1, 2).contiguous().transpose(1, 2) if rng.random() < 0.5 else x
-    o = sfa.flash_attn_fwd(lay(q), lay(k), lay(v), causal=causal, softmax_scale=scale if scale else None,
-                           fast_scale=fast)
-    torch.cuda.synchronize()
+    # head_dim 128: half of the cases on the 4-wave persistent kernel (the library's own choice for large problems only)
+    impl = 40 if D == 128 and rng.random() < 0.5 else -1
+    sfa.debug_set("prefill_impl", impl)
+    try:
+        o = sfa.flash_attn_fwd(lay(q), lay(k), lay(v), causal=causal, softmax_scale=scale if scale else None,
+                               fast_scale=fast)
+        torch.cuda.synchronize()
+    finally:
+        sfa.debug_set("prefill_impl", -1)
     np.testing.assert_allclose(o.float().cpu().numpy(), want, atol=TOL[dtype], rtol=TOL[dtype],
-                               err_msg=f"B={B} Hq={Hq} Hkv={Hkv} Sq={Sq} Sk={Sk} D={D} causal={causal} fast={fast}")
+                               err_msg=f"B={B} Hq={Hq} Hkv={Hkv} Sq={Sq} Sk={Sk} D={D} causal={causal} fast={fast} impl={impl}")
 
 
 @pytest.mark.parametrize("seed", range(24))

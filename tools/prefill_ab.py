@@ -3,7 +3,7 @@
 prefill_dispatch.hip -- -1 auto, 1 8-wave (exact scale), 3 prescaled Q, 10 exact forced, 20-22 128-row,
 40-42 the 4-wave persistent kernel; 0 baseline and 30-32 16x16x32 need the A/B library:
 SFA_LIB_PATH=starflashattention_amd/lib/libStarFlashAttention_ab.so;
-cdna_hip_programming.md rule 24).  usage: python tools/prefill_ab.py [impl ...] [--noncausal] [--d64]"""
+cdna_hip_programming.md rule 24).  usage: python tools/prefill_ab.py [impl ...] [--noncausal] [--d64 | --d256]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ import starflashattention_amd as sfa
 
 impls = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [1, 40]
 causal = "--noncausal" not in sys.argv
-D = 64 if "--d64" in sys.argv else 128
+D = 64 if "--d64" in sys.argv else 256 if "--d256" in sys.argv else 128
 B, H, S = 16, 32, 4096
 for a in sys.argv[1:]:
     if a.startswith("--shape="):          # --shape=B,H,S
