@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
 sfa.debug_set("prefill_impl", int(os.environ.get("IMPL", "-1")))
-B, H, S, D = 16, 32, 4096, 128
+B, H, S, D = 16, 32, 4096, int(os.environ.get("HD", "128"))
 if os.environ.get("SHAPE"):            # SHAPE=B,H,S
     B, H, S = (int(x) for x in os.environ["SHAPE"].split(","))
 dev = torch.device("cuda:0")
