@@ -128,6 +128,7 @@ struct Acc {
     f32x16 o[2][D / 32];        // O^T accumulators (AGPRs)
     float msc[2];               // reference max the exponentials are taken against (log2 units)
     float msafe[2];             // msc, or 0 while a row has seen no key yet (what the scale/subtract uses)
+    float thr[2];               // exact flavour: msc + kThr, the lazy-rescale trigger (kept so the per-half-step test is mul + compare)
     float lsum[2];              // this lane's share of the running row sum
     float alpha[2];             // a rescale of O decided but not yet applied (see hstep); 1 = none
     uint32_t pk[2][8];          // P^T of the half-tile being consumed, packed: pk[q][4k .. 4k+3] = B operand of k-step k
@@ -234,16 +235,17 @@ __device__ __forceinline__ void decide(Acc<D> &acc, int q, f32x16 &s, float mxl,
         return;
     }
     // (a row's two lanes share msc, so the trigger needs no cross-lane exchange)
-    if (__any(mxl * c2 > acc.msc[q] + kThr)) {                  // rare after the first tiles
+    if (__any(mxl * c2 > acc.thr[q])) {                         // rare after the first tiles
         const float mx = half_max(mxl) * c2;                    // both lane halves hold the same query
         const float mnew = fmaxf(acc.msc[q], mx);
         const float al = (mnew == ninf()) ? 1.0f : fast_exp2(acc.msc[q] - mnew);
         acc.msc[q] = mnew;
+        acc.thr[q] = mnew + kThr;
+        acc.msafe[q] = (mnew == ninf()) ? 0.f : mnew;
         acc.lsum[q] *= al;
         acc.alpha[q] = al;
         pend = 1;
     }
-    acc.msafe[q] = (acc.msc[q] == ninf()) ? 0.f : acc.msc[q];
 }
 
 // Apply the rescales of O decided during the previous half-step (wave-uniform, rare).
@@ -272,6 +274,7 @@ __device__ __forceinline__ void lead_in(Acc<D> &acc, f32x16 (&s)[2], float c2, i
             for (int r = 0; r < 16; ++r) { s[q][r] -= m0; acc.cinit[q][r] = -m0; }
         } else {
             acc.msc[q] = mx * c2;
+            acc.thr[q] = acc.msc[q] + kThr;
             acc.msafe[q] = (mx == ninf()) ? 0.f : acc.msc[q];
         }
     }
@@ -769,6 +772,7 @@ prefill_w4_kernel(const PrefillKernelParams p) {
                 for (int r = 0; r < 16; ++r) acc.o[q][d][r] = 0.f;
             acc.msc[q] = PS ? 0.f : ninf();
             acc.msafe[q] = 0.f;
+            acc.thr[q] = ninf();
             acc.lsum[q] = 0.f;
             acc.alpha[q] = 1.0f;
 #pragma unroll
