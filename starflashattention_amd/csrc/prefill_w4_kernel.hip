@@ -116,6 +116,7 @@ __device__ __forceinline__ void dma_piece(unsigned lds, unsigned voff, u32x4s sr
 // against a literal and a select per register (prefill_core.h's mask_half builds sixteen key indices first, and
 // hipcc hoists those out of the rare branch into the MFMA gaps).
 __device__ __forceinline__ void mask_keys(f32x16 &s, int kbase, int h2, int lim) {
+    asm volatile("" : "+s"(kbase));                     // (opaque: hipcc otherwise hoists the subtract out of the rare branch, into every half-step)
     const int room = lim - kbase - 4 * h2;              // keys with offset <= room stay
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -214,6 +215,10 @@ __device__ __forceinline__ void st_a(f32x16 (&s)[2], float (&lsum)[2], uint32_t 
 // m = max(m, a, b), in place among the MFMAs (and without the canonicalising v_max hipcc puts in front of fmaxf)
 __device__ __forceinline__ void st_max3(float &m, const float &a, const float &b) {
     asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b));
+}
+// the first pair of a block: no -inf to start from
+__device__ __forceinline__ void st_max2(float &m, const float &a, const float &b) {
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
 }
 
 // The reference max of query block q against freshly computed scores s (masked if need be): decide, and if it
@@ -322,7 +327,7 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
 #pragma unroll
     for (int i = 0; i < PF; ++i) kf[i] = kpre[i];
     asm volatile("" :: "v"(kf[NKS - 1]));   // one wait for all eight K fragments (read >= 8 gaps ago), see the gap loop
-    float m0 = ninf(), m1 = ninf();         // lane max of the new scores, q0 / q1
+    float m0, m1;                           // lane max of the new scores, q0 / q1 (first written in gaps 9 / 17)
     static_for<32>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         // ---- the MFMA of this gap ----
@@ -370,12 +375,14 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
         }
         // ---- row max of the new scores, and their lead stages ----
         if constexpr (n == 9) { if (mask_n & 1) mask_keys(sN[0], kbase_n, h2, lim[0]); }     // wave-uniform, diagonal / ragged tiles only
-        if constexpr (n >= 9 && n <= 16) st_max3(m0, sN[0][2 * (n - 9)], sN[0][2 * (n - 9) + 1]);
+        if constexpr (n == 9) st_max2(m0, sN[0][0], sN[0][1]);
+        if constexpr (n > 9 && n <= 16) st_max3(m0, sN[0][2 * (n - 9)], sN[0][2 * (n - 9) + 1]);
         if constexpr (n == 17) {
             decide<Tr, D, ORD>(acc, 0, sN[0], m0, c2, pend);
             if (mask_n & 2) mask_keys(sN[1], kbase_n, h2, lim[1]);
         }
-        if constexpr (n >= 17 && n <= 24) st_max3(m1, sN[1][2 * (n - 17)], sN[1][2 * (n - 17) + 1]);
+        if constexpr (n == 17) st_max2(m1, sN[1][0], sN[1][1]);
+        if constexpr (n > 17 && n <= 24) st_max3(m1, sN[1][2 * (n - 17)], sN[1][2 * (n - 17) + 1]);
         if constexpr (n == 25) decide<Tr, D, ORD>(acc, 1, sN[1], m1, c2, pend);
         if constexpr (!(ABL & 4)) {
         if constexpr (n >= 23) st_f<Tr, ORD, n - 23>(sN, acc.msafe, c2);         // elements 0..8
