@@ -25,7 +25,7 @@ ARCH = "gfx950"
 
 EXTRA_FLAGS = {}      # per-source extra hipcc flags
 
-KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_w4_kernel.hip", "prefill_d256_kernel.hip",
+KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_w4_kernel.hip", "prefill_w4d_kernel.hip", "prefill_d256_kernel.hip",
                   "prefill_kernel.hip", "prefill_kernel_bm128.hip", "prefill_dispatch.hip",
                   "aux_kernels.hip", "c_api.hip", "cxx_surface.hip"]
 # Earlier kernel generations kept for A/B runs (tools/prefill_ab.py, pytest -m variants).  They are never an

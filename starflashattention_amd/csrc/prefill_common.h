@@ -54,7 +54,10 @@ int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_di
 // the 4-wave persistent kernel (prefill_w4_kernel.hip); force: 0 = flavour by policy, 1 = prescaled, 2 = exact
 int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
                       int force = 0);
-// head_dim 256 (prefill_d256_kernel.hip)
+// head_dim 256: the one-wave-per-SIMD persistent kernel (prefill_w4d_kernel.hip) wherever one head's rows fit its
+// 32-bit buffer descriptors, the compiler-scheduled kernel (prefill_d256_kernel.hip) otherwise
+int launch_prefill_w4d(const PrefillKernelParams &p, int dtype, bool causal, hipStream_t stream);
+bool prefill_w4d_serves(const PrefillKernelParams &p);
 int launch_prefill_d256(const PrefillKernelParams &p, int dtype, bool causal, hipStream_t stream);
 // q-tiles (256 rows) a full-attention problem must have before the auto rule picks the persistent kernel: one per CU
 constexpr long long kW4MinTiles = 256;

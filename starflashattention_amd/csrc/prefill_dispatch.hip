@@ -1,5 +1,6 @@
 // Picks the prefill kernel.
-//   head_dim 256: prefill_d256_kernel.hip, always.
+//   head_dim 256: prefill_w4d_kernel.hip (the 4-wave persistent structure, 32 query rows per wave); prefill_d256_kernel.hip
+//     (compiler-scheduled) only when a head's rows do not fit 32-bit buffer descriptors, or forced with prefill_impl 61.
 //   auto (default), head_dim 128:
 //     the 4-wave persistent kernel (prefill_w4_kernel.hip: one wave per SIMD, 64 query rows per wave,
 //     O^T in the accumulator file, K/V by LDS-DMA, 256 persistent workgroups) whenever the problem
@@ -25,8 +26,11 @@
 namespace sfa {
 
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
-    if (head_dim == 256) return launch_prefill_d256(p, dtype, causal, stream);      // its own (only) kernel
     int which = g_knobs.prefill_impl.load(std::memory_order_relaxed);
+    if (head_dim == 256) {      // the persistent kernel; 61 forces the compiler-scheduled one (tests, A/B)
+        if (which != 61 && prefill_w4d_serves(p)) return launch_prefill_w4d(p, dtype, causal, stream);
+        return launch_prefill_d256(p, dtype, causal, stream);
+    }
     if (which < 0) {
         const long long nq = (p.Sq + 255) / 256;
         const long long qtiles = (long long)p.B * p.Hq * nq;

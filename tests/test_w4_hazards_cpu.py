@@ -39,15 +39,19 @@ def test_checker_sees_both_hazards_and_nothing_else():
         os.unlink(f.name)
 
 
-def test_compiled_w4_kernel_has_no_unpadded_mfma_hazard():
-    src = os.path.join(ROOT, "starflashattention_amd", "csrc", "prefill_w4_kernel.hip")
+import pytest
+
+
+@pytest.mark.parametrize("name,mfmas", [("prefill_w4_kernel", 500), ("prefill_w4d_kernel", 300)])
+def test_compiled_w4_kernel_has_no_unpadded_mfma_hazard(name, mfmas):
+    src = os.path.join(ROOT, "starflashattention_amd", "csrc", name + ".hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "w4.s")
         r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + ROOT, "-S", "--cuda-device-only",
                             src, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         text = open(out).read()
-        assert text.count("v_mfma_f32_32x32x16") > 500          # the kernels are really in there
-        assert chk.check(out, "prefill_w4_kernel") == 0
+        assert text.count("v_mfma_f32_32x32x16") > mfmas        # the kernels are really in there
+        assert chk.check(out, name) == 0
         # the register files stay where the design puts them: no scratch, no VGPR spills
         assert ".vgpr_spill_count: 0" in text and "scratch_" not in text
