@@ -14,7 +14,7 @@
 //                   softmax stages of S(t) (one element per gap: 16 per lane and tile), V(t)^T reads (two per gap)
 //                   O^T += V(t)^T P(t)^T  (gaps 16-31: k-step 0 x 8 d-blocks, k-step 1 x 8 d-blocks)
 //                   row max of S(t+1) (gaps 17-24), lazy-rescale decision (25), its first stages (26-31)
-//                   K(t+2) fragment reads (gaps 16-31), the LDS-DMA pieces of V(t+2), K(t+4) (gaps 0-7)
+//                   K(t+2) fragment reads (gaps 16-31), the LDS-DMA pieces of V(t+2), K(t+4) (gaps 16-23)
 //     barrier(t) makes K(t+2) and V(t) visible; the slots of K(t+1) and V(t-1) are free by then.  A step is shorter than
 //     an HBM round trip, so the producer runs K FOUR and V two stream positions ahead and a barrier waits only for the
 //     pieces issued two steps back (s_waitcnt vmcnt(8)).
@@ -129,8 +129,8 @@ __device__ __forceinline__ void lead_in(Acc &acc, f32x16 &s, float c2, bool mask
 //   sO  = scores of the tile whose V is at vbuf, in the entry state: finished, multiplied with V^T into acc.o,
 //   and sN is left in the entry state for the next step.
 // mask_n: sN holds keys that must be masked (diagonal / ragged tiles); kbase_n = their first key.
-// kf in: the 16 K fragments of this step; out (PREF): those of the next one (the tile at kbuf_pref).
-template <class Tr, class L, bool PREF, class Hook>
+// kf in: the 16 K fragments of this step; out: those of the next one (the tile at kbuf_pref).
+template <class Tr, class L, class Hook>
 __device__ __forceinline__ void step(const lds_char *lds, unsigned k_e, unsigned v_e, int vbuf, int kbuf_pref,
                                      const typename Tr::mfma_vec (&qf)[NKS], f32x16 &sN, f32x16 &sO, Acc &acc, int &pend,
                                      float c2, bool mask_n, int kbase_n, int h2, int lim, typename Tr::mfma_vec (&kf)[NKS],
@@ -171,7 +171,7 @@ __device__ __forceinline__ void step(const lds_char *lds, unsigned k_e, unsigned
         if constexpr (n < 16) {
             vlo[n] = ld_vt(n, 0);
             vhi[n] = ld_vt(n, 1);
-        } else if constexpr (PREF) {
+        } else {
             kf[n - 16] = ld_kp(n - 16);          // (in place: fragment i was last used in gap i)
         }
         // one s_waitcnt per batch of V fragments instead of one per MFMA
@@ -501,31 +501,31 @@ prefill_w4d_kernel(const PrefillKernelParams p) {
         if (ntw > 0) lead_in<Tr>(acc, sA, c2, 0 > whole, h2, lim);
 
         // ---- FULL steps: this wave needs the next tile as well.  sA / sB alternate as "being consumed" / "being scored":
-        //   barrier(t)  -- K(t+2), V(t) visible; the slots of K(t+1), V(t-1) free: V(t+2), K(t+4) are issued in gaps 0-7
+        //   barrier(t)  -- K(t+2), V(t) visible; the slots of K(t+1), V(t-1) free: V(t+2), K(t+4) are issued in gaps 16-23
         //   step(t):    S(t+1) = K(t+1) Q^T || softmax(S(t)), O += P(t) V(t) || K(t+2) fragments -> registers
-        auto dma_hook = [&](int n) {                            // one piece per gap: V pieces, then K pieces
-            if (n < NJ) produce_v_piece(n);
-            else if (n < 2 * NJ) produce_k_piece(n - NJ);
+        auto dma_hook = [&](int n) {                            // one piece per gap of the (lighter) PV half: V pieces, then K pieces
+            if (n >= 16 && n < 16 + NJ) produce_v_piece(n - 16);
+            else if (n >= 16 + NJ && n < 16 + 2 * NJ) produce_k_piece(n - 16 - NJ);
         };
         int t = 0;
         // sA holds S(t) at every loop boundary; inside a pair of steps the roles alternate STATICALLY (a run-time
         // choice between (sA, sB) and (sB, sA) made hipcc spill 150 registers), and an odd step copies sB back.
-#define SFA_W4D_STEP(PREFV, SNEW, SCUR)                                                                              \
+#define SFA_W4D_STEP(SNEW, SCUR)                                                                                     \
         do {                                                                                                         \
             const int kb1 = (t + 1) * kKeys;                                                                         \
             const int kpref = ring_next(ring_next(kcur));                                                            \
             wait_and_sync();                                                                                         \
-            step<Tr, L, PREFV>(lds, k_e, v_e, vcur, kpref, qf, SNEW, SCUR, acc, pend, c2, kb1 > whole, kb1, h2, lim, kf, dma_hook);  \
+            step<Tr, L>(lds, k_e, v_e, vcur, kpref, qf, SNEW, SCUR, acc, pend, c2, kb1 > whole, kb1, h2, lim, kf, dma_hook);  \
             kcur = ring_next(kcur);                                                                                  \
             vcur = ring_next(vcur);                                                                                  \
             ++t;                                                                                                     \
         } while (0)
         while (t + 2 < ntw) {                                   // two full steps
-            SFA_W4D_STEP(true, sB, sA);
-            SFA_W4D_STEP(true, sA, sB);
+            SFA_W4D_STEP(sB, sA);
+            SFA_W4D_STEP(sA, sB);
         }
         if (t + 1 < ntw) {
-            SFA_W4D_STEP(true, sB, sA);
+            SFA_W4D_STEP(sB, sA);
             sA = sB;
         }
         // ---- LAST tile of this wave: no new scores ----
