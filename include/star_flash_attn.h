@@ -204,7 +204,7 @@ int sfa_prefill_fwd(const sfa_prefill_args *args, void *stream);
 /* The launch paths read no environment variable; the test-suite and tools/ select kernel
  * variants through this call.  knob: "prefill_impl" (-1 auto; kernel generation, see
  * csrc/prefill_dispatch.hip), "prefill_pairs" (1/2), "decode_nt" (0/1), "decode_gqa_mfma" (0/1),
- * "bm128_one_wg" (0/1), "w4_ring".  value -1 = the library's own choice.  Process-wide. */
+ * "bm128_one_wg" (0/1).  value -1 = the library's own choice.  Process-wide. */
 int sfa_debug_set(const char *knob, int value);
 
 /* ---- small helpers the reference's C++ harness uses ----------------------------- */

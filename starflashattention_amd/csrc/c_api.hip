@@ -90,7 +90,6 @@ int sfa_debug_set(const char *knob, int value) {
     else if (!strcmp(knob, "decode_nt")) k = &g_knobs.decode_nt;
     else if (!strcmp(knob, "decode_gqa_mfma")) k = &g_knobs.decode_gqa_mfma;
     else if (!strcmp(knob, "bm128_one_wg")) k = &g_knobs.bm128_one_wg;
-    else if (!strcmp(knob, "w4_ring")) k = &g_knobs.w4_ring;
     else return fail(SFA_ERR_BAD_SHAPE, "sfa_debug_set: unknown knob '%s'", knob);
     k->store(value, std::memory_order_relaxed);
     return SFA_OK;
