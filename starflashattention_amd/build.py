@@ -31,7 +31,7 @@ KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma
 # Earlier kernel generations kept for A/B runs (tools/prefill_ab.py, pytest -m variants).  They are never an
 # auto choice of launch_prefill, so the shipping library does not carry them: build_lib(variants=True)
 # compiles them (and -DSFA_WITH_VARIANTS) into a second library, libStarFlashAttention_ab.so.
-VARIANT_SOURCES = ["prefill_kernel16.hip", "prefill_baseline.hip"]
+VARIANT_SOURCES = ["prefill_kernel16.hip", "prefill_baseline.hip", "prefill_w4r2_kernel.hip"]
 AB_LIB_NAME = "libStarFlashAttention_ab.so"
 
 

@@ -54,6 +54,12 @@ int launch_prefill_baseline(const PrefillKernelParams &p, int dtype, int head_di
 // the 4-wave persistent kernel (prefill_w4_kernel.hip); force: 0 = flavour by policy, 1 = prescaled, 2 = exact
 int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
                       int force = 0);
+// whether one head's Q / K / V rows fit the 32-bit buffer descriptors of the 4-wave kernel (else: the 8-wave kernel)
+bool prefill_w4_serves(const PrefillKernelParams &p, int head_dim);
+// round 2's generation of the 4-wave kernel (q-tiles scored and finished outside the pipeline) and its stamping /
+// ablation builds: the A/B library only (prefill_w4r2_kernel.hip)
+int launch_prefill_w4r2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,
+                        int force = 0);
 // head_dim 256: the one-wave-per-SIMD persistent kernel (prefill_w4d_kernel.hip) wherever one head's rows fit its
 // 32-bit buffer descriptors, the compiler-scheduled kernel (prefill_d256_kernel.hip) otherwise
 int launch_prefill_w4d(const PrefillKernelParams &p, int dtype, bool causal, hipStream_t stream);

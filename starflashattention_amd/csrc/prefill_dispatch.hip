@@ -38,7 +38,7 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
         // (tools/prefill_crossover.sh): full attention from 256 q-tiles on (+5..20 %); under the causal
         // mask only long rows pay -- 16 q-tiles per head and 2048 in all, or 32 per head and 1024 in all
         // (+2..5 %; at seqlen 2048 and below its per-q-tile fixed costs lose 5..15 %).
-        const bool w4 = head_dim == 128 && (causal ? ((nq >= 16 && qtiles >= 2048) || (nq >= 32 && qtiles >= 1024))
+        const bool w4 = prefill_w4_serves(p, head_dim) && (causal ? ((nq >= 16 && qtiles >= 2048) || (nq >= 32 && qtiles >= 1024))
                                                    : qtiles >= kW4MinTiles);
         if (w4) {
             which = 40;
@@ -53,11 +53,12 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
 #ifdef SFA_WITH_VARIANTS
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
     if (which >= 30 && which <= 32) return launch_prefill_x16(p, dtype, head_dim, causal, stream, which - 30);
+    if (which >= 80 && which <= 119) return launch_prefill_w4r2(p, dtype, head_dim, causal, stream, which - 80);
 #else
-    if (which == 0 || (which >= 30 && which <= 32))
+    if (which == 0 || (which >= 30 && which <= 32) || (which >= 80 && which <= 119))
         return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d needs the A/B build of the library (build_lib(variants=True))", which);
 #endif
-    if (which >= 40 && which <= 79) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
+    if (which >= 40 && which <= 44) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
     if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
     if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic (prefill_impl 56: the q-tile stamping build of the 4-wave kernel): where the life of a q-tile goes,
+"""Diagnostic (prefill_impl 96, round 2 kernel, A/B library: the q-tile stamping build of the 4-wave kernel): where the life of a q-tile goes,
 per wave of workgroup 8, over its first 16 q-tiles.  usage: [--noncausal]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
-impl = 59 if "--qpre" in sys.argv else 56
+impl = 99 if "--qpre" in sys.argv else 96
 for a in sys.argv[1:]:
     if a.startswith("--impl="):          # the stamping builds of the ablations (A/B library): 61 empty descriptors, 62 no DMA,
         impl = int(a.split("=")[1])      # 63 no softmax, 64 MFMAs only, 65 everything but the load instruction

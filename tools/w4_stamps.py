@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic (prefill_impl 44: the stamping build of the 4-wave kernel): where a step's cycles go, per wave,
+"""Diagnostic (prefill_impl 84, A/B library: the stamping build of the 4-wave kernel): where a step's cycles go, per wave,
 steps 8..15 of the first item of workgroup 8.  Stamps: 0 H1 start, 1 H1 end, 2 DMA wait over (vmcnt),
 3 barrier passed, 4 H2 end.  usage: [--noncausal]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starflashattention_amd as sfa
-sfa.debug_set("prefill_impl", 44)
+sfa.debug_set("prefill_impl", 84)
 B, H, S, D = 16, 32, 4096, 128
 causal = "--noncausal" not in sys.argv
 dev = torch.device("cuda:0")
