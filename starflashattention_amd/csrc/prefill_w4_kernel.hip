@@ -107,16 +107,19 @@ __device__ __forceinline__ void own_qk(f32x16 &s, typename Tr::mfma_vec k) {
     if constexpr (Tr::id == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "n"(QB), "n"(QB + 3) : SFA_AOWN);
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "n"(QB), "n"(QB + 3) : SFA_AOWN);
 }
-// o (a[OB:OB+15]) [+]= v (VGPR) . p (VGPR); FIRST: the first P.V product of a q-tile starts O from zero
-template <class Tr, int OB, bool FIRST>
+// o (a[OB:OB+15]) += v (VGPR) . p (VGPR)
+template <class Tr, int OB>
 __device__ __forceinline__ void own_pv(typename Tr::mfma_vec v, typename Tr::mfma_vec pfrag) {
-    if constexpr (FIRST) {
-        if constexpr (Tr::id == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, 0" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
-    } else {
-        if constexpr (Tr::id == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
-    }
+    if constexpr (Tr::id == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
+    else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pfrag), "n"(OB), "n"(OB + 15) : SFA_AOWN);
+}
+// o (a[OB:OB+15]) = 0, by the matrix pipe: one instruction instead of sixteen v_accvgpr_write, in a pipe that idles
+// during the epilogue anyway.  The next q-tile's P.V products then simply accumulate (no "first product" variant of the
+// half-step).  z = four registers of zeros, possibly just written: two wait states (hazard (2)).
+template <class Tr, int OB>
+__device__ __forceinline__ void own_zero(typename Tr::mfma_vec z) {
+    if constexpr (Tr::id == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" :: "v"(z), "n"(OB), "n"(OB + 15) : SFA_AOWN);
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c1:%c2], %0, %0, 0" :: "v"(z), "n"(OB), "n"(OB + 15) : SFA_AOWN);
 }
 // every MFMA issued so far has drained after 32 wait states (hazard (1)): in front of any VALU access to a0..a191
 __device__ __forceinline__ void own_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: SFA_AOWN); }
@@ -315,14 +318,16 @@ __device__ __forceinline__ f32x16 mask_tuple(int kbase, int qrow0, int klast) {
 //   OLD 0: nothing to consume (a wave joining the next q-tile after idling behind its diagonal)
 //   and sN is left in the entry state for the next half-step.
 // mask_n bit q: sN[q] holds keys that must be masked (diagonal / ragged tiles); kbase_n = their first key;
-// qbase_n / klast: see mask_tuple (of the q-tile sN belongs to).
+// qbase_n / klast: see mask_tuple (of the q-tile sN belongs to); diag0 = mask_tuple(0, 0, huge): the mask of a 32 x 32
+// block on the causal diagonal; ninf16: sixteen times -inf.
 // kpre in: the K fragments of this half-step; out: those of the next one (rows [32*PH, +32) of the tile at
 // kbuf_pref).  hook(n): extra work for gap n (the LDS-DMA pieces of H2).
-template <class Tr, int D, int ORD, int HO, int PH, int NEW, int OLD, bool FIRST, bool MASK = true, class Hook = NoHook>
+template <class Tr, int D, int ORD, int HO, int PH, int NEW, int OLD, bool MASK, class Hook = NoHook>
 __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigned v_e, int vbuf, int kbuf_pref,
                                       f32x16 (&sN)[2], f32x16 (&sO)[2],
                                       Acc<D> &acc, Fin &fin, int &pend, float c2, int mask_n, int kbase_n, int qbase_n,
-                                      int klast, typename Tr::mfma_vec (&kpre)[D / 16], const Hook &hook = Hook()) {
+                                      int klast, const f32x16 &diag0, const f32x16 &ninf16, typename Tr::mfma_vec (&kpre)[D / 16],
+                                      const Hook &hook = Hook()) {
     using Vec = typename Tr::mfma_vec;
     constexpr int NKS = D / 16, NDB = D / 32;
     constexpr int RG = Img<D>::RG;
@@ -342,7 +347,7 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
             (lds_i16x4 *)((e ? vb_1 : vb_0) + RG * (2 * s + e) + 512 * d)));
     };
 
-    if constexpr (OLD && !FIRST) apply_pending<D>(acc, pend);
+    if constexpr (OLD != 0) apply_pending<D>(acc, pend);
 
     Vec kf[NKS];
     u32x2 vlo[2 * NDB], vhi[2 * NDB];
@@ -363,17 +368,27 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
                     // q-tile's inner tiles.  MASK true (a few half-steps per q-tile): the C operand is a tuple, zeros unless
                     // a block of this half-tile is masked (wave-uniform branch AROUND the mask's arithmetic, no diamond)
                     if constexpr (MASK) {
+                        // ONE MFMA statement whose C tuple is picked by copies (16 v_mov a path): four statements behind a
+                        // four-way branch would do without them, but these half-steps run three times per wave and q-tile
+                        const int qrow0 = qbase_n + 32 * q;
                         f32x16 cm;
-                        if constexpr (PS && NEW == 1) {
-                            cm = acc.cinit[q];
+                        if (!(mask_n & (1 << q))) {
+                            if constexpr (PS && NEW == 1) {
+                                cm = acc.cinit[q];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) cm[r] = 0.f;
+                            }
+                        } else if (kbase_n > min(klast, qrow0 + 31)) {          // no row of the block sees any of these keys
+                            cm = ninf16;
+                        } else if (!(PS && NEW == 1) && kbase_n == qrow0 && kbase_n + 31 <= klast) {
+                            cm = diag0;                                         // the aligned causal diagonal
                         } else {
+                            cm = mask_tuple(kbase_n, qrow0, klast);
+                            if constexpr (PS && NEW == 1) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) cm[r] = 0.f;
-                        }
-                        if (mask_n & (1 << q)) {
-                            const f32x16 mk = mask_tuple(kbase_n, qbase_n + 32 * q, klast);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) cm[r] += mk[r];
+                                for (int r = 0; r < 16; ++r) cm[r] += acc.cinit[q][r];
+                            }
                         }
                         own_qk_first_c<Tr, q_reg(q, 0)>(sN[q], kf[0], cm);
                     } else if constexpr (PS && NEW == 1) {
@@ -391,7 +406,7 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
             av[0] = vlo[j][0]; av[1] = vlo[j][1]; av[2] = vhi[j][0]; av[3] = vhi[j][1];
             pv[0] = acc.pk[q][4 * ks + 0]; pv[1] = acc.pk[q][4 * ks + 1];
             pv[2] = acc.pk[q][4 * ks + 2]; pv[3] = acc.pk[q][4 * ks + 3];
-            own_pv<Tr, o_reg(q, d), FIRST && ks == 0>(bitcast<Vec>(av), bitcast<Vec>(pv));
+            own_pv<Tr, o_reg(q, d)>(bitcast<Vec>(av), bitcast<Vec>(pv));
         }
         // ---- one LDS read ----
         if constexpr (n < 16) {
@@ -448,16 +463,26 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
 // The kernel reads them through a LAUNDERED kernarg pointer wherever a q-tile begins or ends (arg() below): hipcc
 // otherwise loads every field at kernel entry and keeps ~60 scalars alive through the half-step loop, spilling the
 // loop's own scalars to VGPR lanes (v_readlane / v_writelane in the MFMA gaps).
+struct W4CurArgs {       // what a cursor step needs (read in ONE burst where a cursor moves to its next q-tile)
+    int adv_hl, adv_i, adv_b, adv_h;    // one cursor step (= nslots units): heads, units, batches, heads mod Hq
+    int U, Hq, bh_per_xcd, BH, nq, Sk, coff, G;     // U = units per head; G = query heads per K/V head
+};
+struct W4DescArgs {      // what the K / V buffer descriptors of a head need
+    const uint16_t *k, *v;
+    long long ks0, ks1, vs0, vs1;       // element strides: batch, head
+    unsigned k_rowb, v_rowb;            // bytes between rows
+    int k_extent, v_extent;             // bytes of one head's K / V rows
+};
 struct W4Args {
-    const uint16_t *q, *k, *v;
+    W4CurArgs cur;
+    W4DescArgs kv;
+    const uint16_t *q;
     uint16_t *o;
     float *lse;
-    long long qs0, qs1, ks0, ks1, vs0, vs1, os0, os1, os2;      // element strides: batch, head (and O's row)
-    unsigned q_rowb, k_rowb, v_rowb;                            // bytes between rows
-    int k_extent, v_extent;                                     // bytes of one head's K / V rows
-    int B, Hq, G, Sq, Sk, coff, BH, nq, U, bh_per_xcd;          // G = query heads per K/V head; U = units per head
-    int adv_hl, adv_i, adv_b, adv_h;                            // one cursor step (= nslots units): heads, units, batches, heads mod Hq
-    float c2;                                                   // softmax scale * log2(e)
+    long long qs0, qs1, os0, os1, os2;  // element strides: batch, head (and O's row)
+    unsigned q_rowb;
+    int Sq;
+    float c2;                           // softmax scale * log2(e)
 };
 
 // Which items (q-tiles) a workgroup walks, in which order.  blockIdx & 7 labels the XCD (round-robin
@@ -497,28 +522,43 @@ prefill_w4_kernel(const W4Args args_by_value) {
         asm volatile("" : "+s"(a));
         return a;
     };
+    // (field by field: a struct copy out of the constant address space does not compile on the host pass; hipcc merges the
+    // scalar loads into two or three wide ones all the same)
+    auto load_cur = [](ArgPtr a) __attribute__((always_inline)) -> W4CurArgs {
+        W4CurArgs c;
+        c.adv_hl = a->cur.adv_hl; c.adv_i = a->cur.adv_i; c.adv_b = a->cur.adv_b; c.adv_h = a->cur.adv_h;
+        c.U = a->cur.U; c.Hq = a->cur.Hq; c.bh_per_xcd = a->cur.bh_per_xcd; c.BH = a->cur.BH; c.nq = a->cur.nq;
+        c.Sk = a->cur.Sk; c.coff = a->cur.coff; c.G = a->cur.G;
+        return c;
+    };
+    auto load_kv = [](ArgPtr a) __attribute__((always_inline)) -> W4DescArgs {
+        W4DescArgs d;
+        d.k = a->kv.k; d.v = a->kv.v; d.ks0 = a->kv.ks0; d.ks1 = a->kv.ks1; d.vs0 = a->kv.vs0; d.vs1 = a->kv.vs1;
+        d.k_rowb = a->kv.k_rowb; d.v_rowb = a->kv.v_rowb; d.k_extent = a->kv.k_extent; d.v_extent = a->kv.v_extent;
+        return d;
+    };
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
 
-    auto item_tiles = [&](ArgPtr a, int qt) __attribute__((always_inline)) -> int {
-        int kv_end = a->Sk;
-        if (CAUSAL) kv_end = min(a->Sk, qt * kRows + kRows + a->coff);
+    auto item_tiles = [&](const W4CurArgs &a, int qt) __attribute__((always_inline)) -> int {
+        int kv_end = a.Sk;
+        if (CAUSAL) kv_end = min(a.Sk, qt * kRows + kRows + a.coff);
         return kv_end > 0 ? (kv_end + kKeys - 1) / kKeys : 0;
     };
-    auto step_unit = [&](ArgPtr a, W4Cursor &c) __attribute__((always_inline)) {
-        c.i += a->adv_i;
+    auto step_unit = [&](const W4CurArgs &a, W4Cursor &c) __attribute__((always_inline)) {
+        c.i += a.adv_i;
         int carry = 0;
-        if (c.i >= a->U) { c.i -= a->U; carry = 1; }
-        c.hl += a->adv_hl + carry;
-        c.b += a->adv_b;
-        c.h += a->adv_h + carry;
-        if (c.h >= a->Hq) { c.h -= a->Hq; ++c.b; }
+        if (c.i >= a.U) { c.i -= a.U; carry = 1; }
+        c.hl += a.adv_hl + carry;
+        c.b += a.adv_b;
+        c.h += a.adv_h + carry;
+        if (c.h >= a.Hq) { c.h -= a.Hq; ++c.b; }
     };
     // position the cursor on the first existing item at or after (hl, i, sub); skip_empty: also skip items
     // without any tile (causal rows that see no key)
-    auto seek = [&](ArgPtr a, W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
+    auto seek = [&](const W4CurArgs &a, W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
         for (;;) {
-            if (c.hl >= a->bh_per_xcd || xcd * a->bh_per_xcd + c.hl >= a->BH) { c.live = 0; return; }
-            const int heavy = CAUSAL ? a->nq - 1 - c.i : c.i;
+            if (c.hl >= a.bh_per_xcd || xcd * a.bh_per_xcd + c.hl >= a.BH) { c.live = 0; return; }
+            const int heavy = CAUSAL ? a.nq - 1 - c.i : c.i;
             if (c.sub == 0 || (CAUSAL && heavy != c.i)) {
                 c.qt = c.sub == 0 ? heavy : c.i;
                 c.nt = item_tiles(a, c.qt);
@@ -529,17 +569,20 @@ prefill_w4_kernel(const W4Args args_by_value) {
             else { c.sub = 0; step_unit(a, c); }
         }
     };
-    auto next_item_a = [&](ArgPtr a, W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
+    auto next_item_a = [&](const W4CurArgs &a, W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
         if (CAUSAL && c.sub == 0) { c.sub = 1; }
         else { c.sub = 0; step_unit(a, c); }
         seek(a, c, skip_empty);
     };
-    auto next_item = [&](W4Cursor &c, bool skip_empty) __attribute__((always_inline)) { next_item_a(arg(), c, skip_empty); };
+    auto next_item = [&](W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
+        const W4CurArgs ca = load_cur(arg());
+        next_item_a(ca, c, skip_empty);
+    };
     auto first_item = [&](W4Cursor &c, bool skip_empty) __attribute__((always_inline)) {
-        const ArgPtr a = arg();
-        c.hl = slot / a->U; c.i = slot - c.hl * a->U; c.sub = 0; c.t = 0; c.nt = 0; c.qt = 0; c.live = 0;
-        const int bh = xcd * a->bh_per_xcd + c.hl;
-        c.b = bh / a->Hq; c.h = bh - c.b * a->Hq;
+        const W4CurArgs a = load_cur(arg());
+        c.hl = slot / a.U; c.i = slot - c.hl * a.U; c.sub = 0; c.t = 0; c.nt = 0; c.qt = 0; c.live = 0;
+        const int bh = xcd * a.bh_per_xcd + c.hl;
+        c.b = bh / a.Hq; c.h = bh - c.b * a.Hq;
         seek(a, c, skip_empty);
     };
 
@@ -548,7 +591,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
     // 8 rows x 128 B each.  Lane -> (sub-tile lane>>5, row (lane>>2)&7, slot lane&3) of its piece; the source
     // chunk is slot ^ ((row>>2)&3) so that LDS, written linearly, holds the swizzled image.
     const int r8 = (lane >> 2) & 7, dslot = lane & 3, dsub = lane >> 5;
-    const unsigned k_rowb = arg()->k_rowb, v_rowb = arg()->v_rowb;
+    const unsigned k_rowb = arg()->kv.k_rowb, v_rowb = arg()->kv.v_rowb;
     const unsigned kvoff0 = (unsigned)r8 * k_rowb + 64u * dsub + 16u * (dslot ^ (r8 >> 2));
     const unsigned kvoff1 = (unsigned)(r8 + 8) * k_rowb + 64u * dsub + 16u * (dslot ^ (2 + (r8 >> 2)));
     const unsigned vvoff0 = (unsigned)r8 * v_rowb + 64u * dsub + 16u * (dslot ^ (r8 >> 2));
@@ -560,12 +603,12 @@ prefill_w4_kernel(const W4Args args_by_value) {
     // past the sequence end read as zeros.  Per tile the descriptor only moves by one tile's bytes.
     struct Desc { unsigned lo, hi; int left; };
     const int k_tileb = kKeys * (int)k_rowb, v_tileb = kKeys * (int)v_rowb;
-    auto desc_at_head = [&](ArgPtr a, bool is_k, int b, int h) __attribute__((always_inline)) -> Desc {
-        const int hk = a->G == 1 ? h : h / a->G;
-        const uint16_t *head = is_k ? a->k + b * a->ks0 + hk * a->ks1 : a->v + b * a->vs0 + hk * a->vs1;
-        const unsigned skip = 16u * wave * (is_k ? a->k_rowb : a->v_rowb);
+    auto desc_at_head = [&](const W4DescArgs &a, int G, bool is_k, int b, int h) __attribute__((always_inline)) -> Desc {
+        const int hk = G == 1 ? h : h / G;
+        const uint16_t *head = is_k ? a.k + b * a.ks0 + hk * a.ks1 : a.v + b * a.vs0 + hk * a.vs1;
+        const unsigned skip = 16u * wave * (is_k ? a.k_rowb : a.v_rowb);
         const unsigned long long base = (unsigned long long)(uintptr_t)head + skip;
-        return Desc{(unsigned)base, (unsigned)(base >> 32), (is_k ? a->k_extent : a->v_extent) - (int)skip};
+        return Desc{(unsigned)base, (unsigned)(base >> 32), (is_k ? a.k_extent : a.v_extent) - (int)skip};
     };
     auto desc_advance = [&](Desc &d, int tileb) __attribute__((always_inline)) {
         const unsigned lo = d.lo + (unsigned)tileb;
@@ -605,7 +648,13 @@ prefill_w4_kernel(const W4Args args_by_value) {
     first_item(pc, true);
     Desc kd = {0, 0, 0}, vd = {0, 0, 0}, vpend = {0, 0, 0};
     int vpend_live = 0;
-    if (pc.live) { const ArgPtr a = arg(); kd = desc_at_head(a, true, pc.b, pc.h); vd = desc_at_head(a, false, pc.b, pc.h); }
+    if (pc.live) {
+        const ArgPtr a = arg();
+        const W4DescArgs da = load_kv(a);
+        const int G = a->cur.G;
+        kd = desc_at_head(da, G, true, pc.b, pc.h);
+        vd = desc_at_head(da, G, false, pc.b, pc.h);
+    }
     int kring_p = 0, vring_p = 0;               // ring byte offsets the producers write next
     auto ring_next = [](int x) __attribute__((always_inline)) -> int { return x == (kRing - 1) * L::TILE ? 0 : x + L::TILE; };
     // one piece per call (spread over the MFMA gaps of H2): V pieces first, then K pieces
@@ -621,11 +670,13 @@ prefill_w4_kernel(const W4Args args_by_value) {
             desc_advance(kd, k_tileb);
             desc_advance(vd, v_tileb);
         } else {
-            // the producer moves to the next q-tile: ONE read of the arguments (each laundered pointer is its own burst of
-            // scalar loads and its own s_waitcnt, and this runs in an MFMA gap of all four waves at once)
+            // the producer moves to the next q-tile: ONE burst of scalar loads for everything the step and the two
+            // descriptors need, one s_waitcnt (this runs in an MFMA gap of all four waves at once: tools/w4_events.py)
             const ArgPtr a = arg();
-            next_item_a(a, pc, true);
-            if (pc.live) { kd = desc_at_head(a, true, pc.b, pc.h); vd = desc_at_head(a, false, pc.b, pc.h); }
+            const W4CurArgs ca = load_cur(a);
+            const W4DescArgs da = load_kv(a);
+            next_item_a(ca, pc, true);
+            if (pc.live) { kd = desc_at_head(da, ca.G, true, pc.b, pc.h); vd = desc_at_head(da, ca.G, false, pc.b, pc.h); }
         }
     };
     auto produce_k_piece = [&](int idx) __attribute__((always_inline)) {
@@ -657,11 +708,11 @@ prefill_w4_kernel(const W4Args args_by_value) {
     // that many operations in flight.
     int young = 0;
     auto wait_and_sync = [&]() __attribute__((always_inline)) {
-        if (young >= 32) asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
-        else if (young >= 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-        else if (young >= 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-        else if (young >= 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (young < 8) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");         // (the usual case first: one branch)
+        else if (young < 16) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (young < 24) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else if (young < 32) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
         young = 0;                                          // (the K/V pieces of the step follow)
     };
 
@@ -727,7 +778,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
     };
     auto item_w = [&](int qt, int nt, ItemW &w) __attribute__((always_inline)) {
         const ArgPtr a = arg();
-        const int coff = a->coff, Sk = a->Sk;               // causal: key j visible iff j <= i + coff
+        const int coff = a->cur.coff, Sk = a->cur.Sk;       // causal: key j visible iff j <= i + coff
         w.wq0 = qt * kRows + 64 * wave;
         w.qbase = CAUSAL ? w.wq0 + coff : (1 << 29);
         w.klast = Sk - 1;
@@ -798,6 +849,18 @@ prefill_w4_kernel(const W4Args args_by_value) {
         }
     };
 
+    // the additive mask of a 32 x 32 block on the aligned causal diagonal (rows and keys start together): 16 registers
+    // every wave keeps for the whole kernel (it has ~60 to spare), so that the three masked blocks a wave meets per q-tile
+    // cost their MFMA's C operand and nothing else
+    const f32x16 diag0 = mask_tuple(0, 0, 1 << 29);
+    f32x16 ninf16;                              // ... and the mask of a block none of whose keys any row sees
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ninf16[r] = ninf();
+    asm volatile("" : "+v"(ninf16));            // (one tuple kept, not sixteen v_mov wherever it is used)
+    {                                           // O starts from zero; every epilogue leaves it so for the next q-tile
+        const Vec z = bitcast<Vec>(make_uint4(0u, 0u, 0u, 0u));
+        static_for<2 * NDB>([&](auto ic) { own_zero<Tr, 16 * decltype(ic)::value>(z); });
+    }
     Acc<D> acc;
     Fin fin = {{0.f, 0.f}, {0.f, 0.f}};
     int pend = 0;                                           // a rescale of O is parked in acc.alpha (wave-uniform)
@@ -816,7 +879,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
         uint16_t *const obase = a->o + b * a->os0 + h * a->os1;
         const long long os2 = a->os2;
         float *const lse_p = a->lse;
-        const long long lse_row0 = ((long long)b * a->Hq + h) * Sq;
+        const long long lse_row0 = ((long long)b * a->cur.Hq + h) * Sq;
         const int ln = lane_now(), l31 = ln & 31, h2 = ln >> 5;
         const int qrow = w.wq0 + 32 * q + l31;
         float ltot = 0.f;
@@ -856,6 +919,14 @@ prefill_w4_kernel(const W4Args args_by_value) {
                 lse_p[lse_row0 + qrow] = lse;
             }
         }
+        if (have_o) {               // the block's O starts the next q-tile from zero (all lanes: outside the row predicate)
+            const Vec z = bitcast<Vec>(make_uint4(0u, 0u, 0u, 0u));
+            static_for<NDB>([&](auto ic) {
+                constexpr int d = decltype(ic)::value;
+                if (q == 0) own_zero<Tr, o_reg(0, d)>(z);
+                else own_zero<Tr, o_reg(1, d)>(z);
+            });
+        }
         if (w.wq0 + 32 * q + 31 < Sq) young += 8;           // every lane stored: 8 row stores at least
     };
     auto epilogue = [&](int b, int h, const ItemW &w, bool have_o) __attribute__((always_inline)) {
@@ -864,7 +935,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
     };
     // q-tiles without any key (causal rows in front of the first key; Sq > Sk only): O = 0, lse = -inf.  They own no
     // stream position, so they are dealt with up front; the pipeline below walks the q-tiles that have keys.
-    if (CAUSAL && arg()->coff < 0) {
+    if (CAUSAL && arg()->cur.coff < 0) {
         W4Cursor c0;
         first_item(c0, false);
         while (c0.live) {
@@ -903,8 +974,8 @@ prefill_w4_kernel(const W4Args args_by_value) {
             {
                 const int k1 = ring_next(kcur);
                 if (prev_full) {
-                    hstep<Tr, D, ORD, 1, 1, 2, 1, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                          mask_bits(cw, 0), 0, cw.qbase, cw.klast, kpre, dma_hook);
+                    hstep<Tr, D, ORD, 1, 1, 2, 1, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                                                          mask_bits(cw, 0), 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     istamp(5);
                     ev(3, 63);
                     epilogue(pb, ph, pw, true);
@@ -915,8 +986,8 @@ prefill_w4_kernel(const W4Args args_by_value) {
 #pragma unroll
                     for (int i = 0; i < NKS; ++i)
                         kpre[i] = bitcast<Vec>(lds_read16(((i & 1) ? kb_o : kb_e) + 512 * (i >> 1)));
-                    hstep<Tr, D, ORD, 1, 1, 2, 0, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                          mask_bits(cw, 0), 0, cw.qbase, cw.klast, kpre, dma_hook);
+                    hstep<Tr, D, ORD, 1, 1, 2, 0, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                                                          mask_bits(cw, 0), 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     ev(3, 63);
                     if (epi_pending) { epilogue_q(pb, ph, pw, 1, true); epi_pending = false; ev(4, 63); }
                 }
@@ -951,63 +1022,46 @@ prefill_w4_kernel(const W4Args args_by_value) {
             // H1(t): S(B_t) = K(t)[32:64] Q^T  ||  softmax(A_t), O += P(A_t) V(t)[0:32]
             // barrier(t): K(t+2), V(t+1) visible; the slots of K(t), V(t-1) free
             // H2(t): S(A_t+1) = K(t+1)[0:32] Q^T  ||  softmax(B_t), O += P(B_t) V(t)[32:64]  ||  LDS-DMA of K(t+3), V(t+2)
-            // ---- phase A: full steps ----
-            if (ntw > 1) {
-                {
-                    const int k1 = ring_next(kcur);
-                    hstep<Tr, D, ORD, 0, 0, 1, 1, true>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                         mask_bits(cw, 32), 32, cw.qbase, cw.klast, kpre);
-                    wait_and_sync();
-                    hstep<Tr, D, ORD, 1, 1, 1, 1, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                          mask_bits(cw, 64), 64, cw.qbase, cw.klast, kpre, dma_hook);
-                    step_done();
-                }
-                // the inner tiles: no key of theirs needs masking, and the half-steps carry no mask code
+            // ---- phase A: full steps -- the inner tiles: no key of theirs needs masking, and the half-steps carry no
+            // mask code ----
+            {
                 const int t_inner = min(ntw - 1, cw.t_mask);
                 while (t < t_inner) {
                     const int k1 = ring_next(kcur);
-                    hstep<Tr, D, ORD, 0, 0, 1, 1, false, false>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                                 0, 0, 0, 0, kpre);
-                    ev(1, t);
-                    wait_and_sync();
-                    ev(2, t);
-                    hstep<Tr, D, ORD, 1, 1, 1, 1, false, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                                 0, 0, 0, 0, kpre, dma_hook);
-                    ev(3, t);
-                    step_done();
-                }
-                // the tiles at the causal diagonal / the ragged end of the keys
-                while (t + 1 < ntw) {
-                    const int k1 = ring_next(kcur);
-                    const int kbase = t * kKeys;
                     hstep<Tr, D, ORD, 0, 0, 1, 1, false>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                          mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, kpre);
+                                                          0, 0, 0, 0, diag0, ninf16, kpre);
                     ev(1, t);
                     wait_and_sync();
                     ev(2, t);
                     hstep<Tr, D, ORD, 1, 1, 1, 1, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                          mask_bits(cw, kbase + 64), kbase + 64, cw.qbase, cw.klast, kpre, dma_hook);
+                                                          0, 0, 0, 0, diag0, ninf16, kpre, dma_hook);
                     ev(3, t);
                     step_done();
                 }
             }
             istamp(3);
-            // ---- phase B: the first half of this wave's last tile; an early wave finishes the q-tile here ----
+            // ---- phase B: the tiles at the causal diagonal / the ragged end of the keys (full steps still), and the first
+            // half of this wave's last tile; an early wave finishes the q-tile here ----
             if (ntw > 0) {
-                const int k1 = ring_next(kcur);
-                const int kbase = t * kKeys;
-                if (ntw == 1)
+                for (;;) {
+                    const int k1 = ring_next(kcur);
+                    const int kbase = t * kKeys;
                     hstep<Tr, D, ORD, 0, 0, 1, 1, true>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                         mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, kpre);
-                else
-                    hstep<Tr, D, ORD, 0, 0, 1, 1, false>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                          mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, kpre);
-                ev(1, t);
+                                                         mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
+                    ev(1, t);
+                    if (t + 1 == ntw) break;                // the wave's last tile: its second half is the seam's, or ends the q-tile
+                    wait_and_sync();
+                    ev(2, t);
+                    hstep<Tr, D, ORD, 1, 1, 1, 1, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                                                         mask_bits(cw, kbase + 64), kbase + 64, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
+                    ev(3, t);
+                    step_done();
+                }
                 if (!full_wave) {
                     wait_and_sync();
                     ev(2, t);
-                    hstep<Tr, D, ORD, 1, 1, 0, 1, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                          0, 0, cw.qbase, cw.klast, kpre, dma_hook);
+                    hstep<Tr, D, ORD, 1, 1, 0, 1, true>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
+                                                         0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     ev(3, t);
                     // this wave's rows are stored in the time it would otherwise idle: one block now (the working waves
                     // reach the next barrier one half-step from here), the other in the next step -- an idle one, or the
@@ -1041,8 +1095,8 @@ prefill_w4_kernel(const W4Args args_by_value) {
         // ======== the last q-tile of the list: nothing to score behind it ========
         wait_and_sync();
         if (full_wave) {
-            hstep<Tr, D, ORD, 1, 1, 0, 1, false>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
-                                                  0, 0, cw.qbase, cw.klast, kpre, dma_hook);
+            hstep<Tr, D, ORD, 1, 1, 0, 1, true>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
+                                                  0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
             epilogue(cc.b, cc.h, cw, true);
         } else if (epi_pending) {
             epilogue_q(cc.b, cc.h, cw, 1, true);
@@ -1062,17 +1116,20 @@ int launch_w4_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
     const long long units_xcd = (long long)p.bh_per_xcd * U;
     const int nslots = (int)(units_xcd < 32 ? units_xcd : 32);
     W4Args a;
-    a.q = p.q; a.k = p.k; a.v = p.v; a.o = p.o; a.lse = p.lse;
-    a.qs0 = p.qs[0]; a.qs1 = p.qs[1]; a.ks0 = p.ks[0]; a.ks1 = p.ks[1]; a.vs0 = p.vs[0]; a.vs1 = p.vs[1];
-    a.os0 = p.os[0]; a.os1 = p.os[1]; a.os2 = p.os[2];
-    a.q_rowb = (unsigned)(2 * p.qs[2]); a.k_rowb = (unsigned)(2 * p.ks[2]); a.v_rowb = (unsigned)(2 * p.vs[2]);
-    a.k_extent = (int)((long long)(p.Sk - 1) * a.k_rowb + 2 * D);
-    a.v_extent = (int)((long long)(p.Sk - 1) * a.v_rowb + 2 * D);
-    a.B = p.B; a.Hq = p.Hq; a.G = p.Hq / p.Hkv; a.Sq = p.Sq; a.Sk = p.Sk; a.coff = p.Sk - p.Sq;
-    a.BH = p.B * p.Hq; a.nq = nq; a.U = U; a.bh_per_xcd = p.bh_per_xcd;
-    a.adv_hl = nslots / U; a.adv_i = nslots - a.adv_hl * U;
-    a.adv_b = a.adv_hl / p.Hq; a.adv_h = a.adv_hl - a.adv_b * p.Hq;
+    a.q = p.q; a.o = p.o; a.lse = p.lse;
+    a.qs0 = p.qs[0]; a.qs1 = p.qs[1]; a.os0 = p.os[0]; a.os1 = p.os[1]; a.os2 = p.os[2];
+    a.q_rowb = (unsigned)(2 * p.qs[2]);
+    a.Sq = p.Sq;
     a.c2 = p.scale_log2;
+    a.kv.k = p.k; a.kv.v = p.v;
+    a.kv.ks0 = p.ks[0]; a.kv.ks1 = p.ks[1]; a.kv.vs0 = p.vs[0]; a.kv.vs1 = p.vs[1];
+    a.kv.k_rowb = (unsigned)(2 * p.ks[2]); a.kv.v_rowb = (unsigned)(2 * p.vs[2]);
+    a.kv.k_extent = (int)((long long)(p.Sk - 1) * a.kv.k_rowb + 2 * D);
+    a.kv.v_extent = (int)((long long)(p.Sk - 1) * a.kv.v_rowb + 2 * D);
+    a.cur.U = U; a.cur.Hq = p.Hq; a.cur.bh_per_xcd = p.bh_per_xcd; a.cur.BH = p.B * p.Hq; a.cur.nq = nq;
+    a.cur.Sk = p.Sk; a.cur.coff = p.Sk - p.Sq; a.cur.G = p.Hq / p.Hkv;
+    a.cur.adv_hl = nslots / U; a.cur.adv_i = nslots - a.cur.adv_hl * U;
+    a.cur.adv_b = a.cur.adv_hl / p.Hq; a.cur.adv_h = a.cur.adv_hl - a.cur.adv_b * p.Hq;
     dim3 grid(8u * nslots), block(kThreadsW4);
     static DynLdsAttr attr_c, attr_f;
     if (const int rc = causal ? attr_c.ensure(reinterpret_cast<const void *>(&prefill_w4_kernel<Tr, D, true, ORD, DIAG>), lds, "prefill_w4_kernel")
