@@ -322,7 +322,7 @@ __device__ __forceinline__ f32x16 mask_tuple(int kbase, int qrow0, int klast) {
 // block on the causal diagonal; ninf16: sixteen times -inf.
 // kpre in: the K fragments of this half-step; out: those of the next one (rows [32*PH, +32) of the tile at
 // kbuf_pref).  hook(n): extra work for gap n (the LDS-DMA pieces of H2).
-template <class Tr, int D, int ORD, int HO, int PH, int NEW, int OLD, bool MASK, class Hook = NoHook>
+template <class Tr, int D, int ORD, int HO, int PH, int NEW, int OLD, int MK, class Hook = NoHook>
 __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigned v_e, int vbuf, int kbuf_pref,
                                       f32x16 (&sN)[2], f32x16 (&sO)[2],
                                       Acc<D> &acc, Fin &fin, int &pend, float c2, int mask_n, int kbase_n, int qbase_n,
@@ -364,9 +364,20 @@ __device__ __forceinline__ void hstep(const lds_char *lds, unsigned k_e, unsigne
             if constexpr (NEW != 0) {
                 constexpr int q = n >> 3, ks = n & 7;
                 if constexpr (ks == 0) {
-                    // MASK false: the caller knows that no key of this half-tile needs masking -- the half-step loop of a
-                    // q-tile's inner tiles.  MASK true (a few half-steps per q-tile): the C operand is a tuple, zeros unless
-                    // a block of this half-tile is masked (wave-uniform branch AROUND the mask's arithmetic, no diamond)
+                    // MK 0: the caller knows that no key of this half-tile needs masking -- the half-step loop of a q-tile's
+                    //       inner tiles;
+                    // MK 2 / 3: the caller knows WHICH mask each block takes -- the two half-steps in which a wave crosses
+                    //       an aligned causal diagonal (rows and keys of its 64 x 64 corner start together): 2 = query block 0
+                    //       on the diagonal, block 1 unmasked; 3 = block 0 fully masked, block 1 on the diagonal.  The mask
+                    //       tuple is the MFMA's C operand directly: no branch, no copy (exact flavour only);
+                    // MK 1: anything else (unaligned Sk - Sq, ragged tiles, the first scores of a q-tile), a few half-steps
+                    //       per q-tile: the C operand is picked at run time.
+                    constexpr bool MASK = MK == 1;
+                    if constexpr (MK == 2 || MK == 3) {
+                        static_assert(!(PS && NEW == 1) || MK < 2, "the static masks have no room for the prescaled reference");
+                        if constexpr (MK == 2 && q == 1) own_qk_first<Tr, q_reg(q, 0)>(sN[q], kf[0]);
+                        else own_qk_first_c<Tr, q_reg(q, 0)>(sN[q], kf[0], (MK == 3 && q == 0) ? ninf16 : diag0);
+                    } else
                     if constexpr (MASK) {
                         // ONE MFMA statement whose C tuple is picked by copies (16 v_mov a path): four statements behind a
                         // four-way branch would do without them, but these half-steps run three times per wave and q-tile
@@ -775,6 +786,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
         int ntw;            // tiles this wave computes on (wave-uniform; the others it idles through)
         int whole[NQB];     // key index up to which a 32-key half-tile is visible in full to query block q
         int t_mask;         // first step whose half-steps score keys that may need masking (those of tiles t_mask .. )
+        int aligned;        // the wave's last tile is a whole 64 x 64 corner on the causal diagonal (and not its first tile)
     };
     auto item_w = [&](int qt, int nt, ItemW &w) __attribute__((always_inline)) {
         const ArgPtr a = arg();
@@ -790,6 +802,10 @@ prefill_w4_kernel(const W4Args args_by_value) {
         const int wmin = min(w.whole[0], w.whole[1]);
         const int jm = wmin < 0 ? 0 : wmin / 32 + 1;
         w.t_mask = max(0, (jm - 1) >> 1);
+        // rows and keys of the wave's corner start together (wq0 + coff a multiple of 64), the corner is the wave's last
+        // tile, lies inside the keys, and H2 of the step before it exists in this q-tile
+        const int d0 = w.wq0 + coff;
+        w.aligned = CAUSAL && d0 >= 64 && (d0 & 63) == 0 && d0 + 63 <= Sk - 1 && w.ntw == (d0 >> 6) + 1;
     };
     // bit q set: the 32 keys starting at kbase need masking for query block q (wave-uniform)
     auto mask_bits = [&](const ItemW &w, int kbase) __attribute__((always_inline)) -> int {
@@ -955,7 +971,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
         // whether this wave worked up to its last tile (then the previous q-tile's last half-tile is still to be
         // consumed: sB, O, the sums).
         int pb = 0, ph = 0;
-        ItemW pw = {0, 0, 0, 0, {0, 0}, 0};
+        ItemW pw = {0, 0, 0, 0, {0, 0}, 0, 0};
         bool prev_full = false;
         bool epi_pending = false;                           // query block 1 of q-tile (pb, ph, pw) is still to be stored
         ItemW cw;                                           // this wave's view of the current q-tile
@@ -974,7 +990,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
             {
                 const int k1 = ring_next(kcur);
                 if (prev_full) {
-                    hstep<Tr, D, ORD, 1, 1, 2, 1, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                    hstep<Tr, D, ORD, 1, 1, 2, 1, 1>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
                                                           mask_bits(cw, 0), 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     istamp(5);
                     ev(3, 63);
@@ -986,7 +1002,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
 #pragma unroll
                     for (int i = 0; i < NKS; ++i)
                         kpre[i] = bitcast<Vec>(lds_read16(((i & 1) ? kb_o : kb_e) + 512 * (i >> 1)));
-                    hstep<Tr, D, ORD, 1, 1, 2, 0, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                    hstep<Tr, D, ORD, 1, 1, 2, 0, 1>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
                                                           mask_bits(cw, 0), 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     ev(3, 63);
                     if (epi_pending) { epilogue_q(pb, ph, pw, 1, true); epi_pending = false; ev(4, 63); }
@@ -1028,12 +1044,12 @@ prefill_w4_kernel(const W4Args args_by_value) {
                 const int t_inner = min(ntw - 1, cw.t_mask);
                 while (t < t_inner) {
                     const int k1 = ring_next(kcur);
-                    hstep<Tr, D, ORD, 0, 0, 1, 1, false>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
+                    hstep<Tr, D, ORD, 0, 0, 1, 1, 0>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
                                                           0, 0, 0, 0, diag0, ninf16, kpre);
                     ev(1, t);
                     wait_and_sync();
                     ev(2, t);
-                    hstep<Tr, D, ORD, 1, 1, 1, 1, false>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                    hstep<Tr, D, ORD, 1, 1, 1, 1, 0>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
                                                           0, 0, 0, 0, diag0, ninf16, kpre, dma_hook);
                     ev(3, t);
                     step_done();
@@ -1043,24 +1059,45 @@ prefill_w4_kernel(const W4Args args_by_value) {
             // ---- phase B: the tiles at the causal diagonal / the ragged end of the keys (full steps still), and the first
             // half of this wave's last tile; an early wave finishes the q-tile here ----
             if (ntw > 0) {
-                for (;;) {
-                    const int k1 = ring_next(kcur);
-                    const int kbase = t * kKeys;
-                    hstep<Tr, D, ORD, 0, 0, 1, 1, true>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                         mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
+                if (!PS && cw.aligned) {
+                    // the wave crosses an aligned causal diagonal in its last tile: the three masked blocks -- query block 0
+                    // against the tile's first half (scored by H2 of the step before), both blocks against its second half
+                    // -- take their masks as C operands fixed at compile time.  (t == ntw - 2 here.)
+                    {
+                        const int k1 = ring_next(kcur);
+                        hstep<Tr, D, ORD, 0, 0, 1, 1, 0>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
+                                                          0, 0, 0, 0, diag0, ninf16, kpre);
+                        ev(1, t);
+                        wait_and_sync();
+                        ev(2, t);
+                        hstep<Tr, D, ORD, 1, 1, 1, 1, PS ? 1 : 2>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                                                                   1, t * kKeys + 64, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
+                        ev(3, t);
+                        step_done();
+                    }
+                    hstep<Tr, D, ORD, 0, 0, 1, 1, PS ? 1 : 3>(lds, k_e, v_e, vcur, ring_next(kcur), sB, sA, acc, fin, pend, c2,
+                                                               3, t * kKeys + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
                     ev(1, t);
-                    if (t + 1 == ntw) break;                // the wave's last tile: its second half is the seam's, or ends the q-tile
-                    wait_and_sync();
-                    ev(2, t);
-                    hstep<Tr, D, ORD, 1, 1, 1, 1, true>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
-                                                         mask_bits(cw, kbase + 64), kbase + 64, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
-                    ev(3, t);
-                    step_done();
+                } else {
+                    for (;;) {
+                        const int k1 = ring_next(kcur);
+                        const int kbase = t * kKeys;
+                        hstep<Tr, D, ORD, 0, 0, 1, 1, 1>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
+                                                          mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
+                        ev(1, t);
+                        if (t + 1 == ntw) break;            // the wave's last tile: its second half is the seam's, or ends the q-tile
+                        wait_and_sync();
+                        ev(2, t);
+                        hstep<Tr, D, ORD, 1, 1, 1, 1, 1>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
+                                                          mask_bits(cw, kbase + 64), kbase + 64, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
+                        ev(3, t);
+                        step_done();
+                    }
                 }
                 if (!full_wave) {
                     wait_and_sync();
                     ev(2, t);
-                    hstep<Tr, D, ORD, 1, 1, 0, 1, true>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
+                    hstep<Tr, D, ORD, 1, 1, 0, 1, 1>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
                                                          0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     ev(3, t);
                     // this wave's rows are stored in the time it would otherwise idle: one block now (the working waves
@@ -1095,7 +1132,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
         // ======== the last q-tile of the list: nothing to score behind it ========
         wait_and_sync();
         if (full_wave) {
-            hstep<Tr, D, ORD, 1, 1, 0, 1, true>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
+            hstep<Tr, D, ORD, 1, 1, 0, 1, 1>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
                                                   0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
             epilogue(cc.b, cc.h, cw, true);
         } else if (epi_pending) {
