@@ -120,24 +120,81 @@ def bench_decode(torch, sfa, steps, warmup):
 
 def bench_config5_shard(torch, sfa, steps):
     """BASELINE.json configs[4]'s per-GPU shard (batch 128 over 8 GPUs = 16 per GPU): S=8192 non-causal."""
+    ms, tf, name = time_prefill(torch, sfa, 16, 32, 8192, 128, False, steps)
+    return {"workload": "prefill fwd full, B=16 H=32 S=8192 D=128 (BASELINE.json configs[4], one GPU's shard)",
+            "kernel": name, "ms_per_step": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+
+
+def time_prefill(torch, sfa, B, H, S, D, causal, steps, warmup=3, Hkv=None, seed=77):
+    """One prefill shape through the library's own kernel choice: (ms per launch, TFLOPS, kernel name)."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    B, H, S, D = 16, 32, 8192, 128
-    g = torch.Generator(device=dev).manual_seed(77)
-    q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev, dtype=torch.float32).bfloat16() for _ in range(3))
+    g = torch.Generator(device=dev).manual_seed(seed)
+    q = torch.randn((B, H, S, D), generator=g, device=dev, dtype=torch.float32).bfloat16()
+    k, v = (torch.randn((B, Hkv or H, S, D), generator=g, device=dev, dtype=torch.float32).bfloat16() for _ in range(2))
     out = torch.empty_like(q)
-    for _ in range(3):
-        sfa.flash_attn_fwd(q, k, v, causal=False, out=out)
+    for _ in range(warmup):
+        sfa.flash_attn_fwd(q, k, v, causal=causal, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(steps):
-        sfa.flash_attn_fwd(q, k, v, causal=False, out=out)
+        sfa.flash_attn_fwd(q, k, v, causal=causal, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    tf = attn_flops(B, H, S, S, D, False) / (ms * 1e-3) / 1e12
-    return {"workload": "prefill fwd full, B=16 H=32 S=8192 D=128 (BASELINE.json configs[4], one GPU's shard)",
-            "ms_per_step": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+    name = sfa.last_prefill_kernel()
+    del q, k, v, out
+    torch.cuda.empty_cache()
+    return ms, attn_flops(B, H, S, S, D, causal) / (ms * 1e-3) / 1e12, name
+
+
+def bench_other_prefill(torch, sfa, steps):
+    """The kernels the headline does not exercise (round-2 verdict item 5), never `value`:
+    BASELINE.json configs[1] (head_dim 64, the 8-wave / 128-row kernels) and head_dim 256."""
+    out = {}
+    for key, (B, H, S, D, causal, what) in {
+            "config2_bringup": (8, 16, 1024, 64, False, "prefill fwd full, B=8 H=16 S=1024 D=64 (BASELINE.json configs[1])"),
+            "prefill_d256": (8, 16, 4096, 256, True, "prefill fwd causal, B=8 H=16 S=4096 D=256"),
+    }.items():
+        try:
+            ms, tf, name = time_prefill(torch, sfa, B, H, S, D, causal, max(steps, 20) if S <= 1024 else steps)
+            out[key] = {"workload": what, "kernel": name, "ms_per_step": round(ms, 4), "achieved": round(tf, 2),
+                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "bound": "mfma"}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
+    return out
+
+
+def bench_decode_gqa(torch, sfa, steps):
+    """Grouped-query decode, B=256 Hq=32 Hkv=4 Sk=8192 D=128 bf16: the cache is streamed once per KV head
+    (decode_gqa_mfma_kernel); algorithmic bytes = K + V rows once + qkv + o."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, H, Hkv, Sk, D = 256, 32, 4, 8192, 128
+    M = Sk
+    kc = torch.randn((B, 1, M, Hkv, D), device=dev, dtype=torch.float32).bfloat16()
+    vc = torch.randn((B, 1, M, Hkv, D), device=dev, dtype=torch.float32).bfloat16()
+    qkv = torch.randn((B, H + 2 * Hkv, D), device=dev).bfloat16()
+    o = torch.empty((B, H, D), dtype=torch.bfloat16, device=dev)
+    sl = torch.full((B,), Sk - 1, dtype=torch.int32, device=dev)
+    z = torch.zeros(0, dtype=torch.bfloat16, device=dev)
+    run = lambda: sfa.flash_decode(qkv, z, z, z, kc, vc, sl, o, B, M, H, D, D, M, 1, 0, num_heads_kv=Hkv)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    nbytes = 2.0 * B * Sk * Hkv * D * 2 + (H + 2 * Hkv + H) * B * D * 2
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    del kc, vc
+    torch.cuda.empty_cache()
+    return {"workload": "decode B=256 Sq=1 Sk=8192 Hq=32 Hkv=4 D=128 bf16 (grouped queries on the matrix cores)",
+            "ms_per_step": round(ms, 4), "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(gbps / PEAK_HBM_GBPS, 4), "bound": "hbm", "algorithmic_bytes": nbytes}
 
 
 def bench_gemm_calibration(torch):
@@ -186,6 +243,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] shard under --gpus N > 1")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -242,8 +300,20 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps          # avg launch duration (back-to-back launches)
-    from starflashattention_amd.sharding import aggregate_throughput, max_over_ranks
+    kernel_name = sfa.last_prefill_kernel()               # what the dispatcher launched, not a string literal
+    from starflashattention_amd.sharding import aggregate_throughput, gather_over_ranks, max_over_ranks
+    per_rank_ms = gather_over_ranks(elapsed / args.steps * 1e3, dist, dev)     # (devices of one node differ by several %)
     elapsed = max_over_ranks(elapsed, dist, dev)          # the job is as slow as its slowest rank
+    # BASELINE.json configs[4] is the multi-GPU workload proper (B=128 S=8192 non-causal over 8 GPUs = B=16 per GPU):
+    # under --gpus N every rank also times its shard of it; still no data-path collective
+    c5 = None
+    if world > 1 and not args.no_config5:
+        c5_steps = min(10, max(3, args.steps // 4))
+        if dist is not None:
+            dist.barrier()
+        c5_ms, _, c5_name = time_prefill(torch, sfa, 16, 32, 8192, 128, False, c5_steps, seed=77 + rank)
+        c5_all = gather_over_ranks(c5_ms, dist, dev)
+        c5 = (c5_all, c5_name)
 
     flops_step = attn_flops(B, H, S, S, D, causal)        # per rank
     total_tflops = aggregate_throughput(flops_step, args.steps, elapsed, world) / 1e12
@@ -251,7 +321,7 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = None, None
-        for name in ("r02_hbm_traffic.json",):      # committed PMC measurement of this same command (tools/profile_bench.sh)
+        for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):   # committed PMC measurement of this same command (tools/profile_bench.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["prefill_kernel"]["total_bytes"]
@@ -272,12 +342,22 @@ def main():
                        "causal": causal, "parallelism": f"batch-shard x{world}"},
             "tflops_per_gpu": round(total_tflops / world, 2),
             "frac_mfma_peak": round(total_tflops / world / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "prefill_w4_kernel<Bf16,128,causal,exact>",
+            "per_rank_ms": {"headline": [round(x, 4) for x in per_rank_ms]},
+            "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": round(kern_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(kern_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops_step},
         }
+        if c5 is not None:
+            c5_all, c5_name = c5
+            f5 = attn_flops(16, 32, 8192, 8192, 128, False)
+            tot = world * f5 / (max(c5_all) * 1e-3) / 1e12          # all ranks' work over the slowest rank's time
+            rec["config5"] = {"workload": "prefill fwd full, B=16 H=32 S=8192 D=128 per GPU = BASELINE.json configs[4] "
+                                          f"(B=128 over 8 GPUs) at {world} of its 8 shards; batch-sharded, no collectives",
+                              "kernel": c5_name, "tflops_total": round(tot, 2), "tflops_per_gpu": round(tot / world, 2),
+                              "frac_mfma_peak": round(tot / world / PEAK_BF16_TFLOPS, 4)}
+            rec["per_rank_ms"]["config5"] = [round(x, 4) for x in c5_all]
         if world == 1:
             # supplementary, NOT the headline: the opt-in prescaled-Q kernels (fast_scale=True)
             try:
@@ -304,6 +384,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 rec["config5_shard"] = {"error": repr(e)[:200]}
+            rec.update(bench_other_prefill(torch, sfa, min(20, max(3, args.steps // 4))))
+            try:
+                rec["decode_gqa"] = bench_decode_gqa(torch, sfa, min(30, max(3, args.steps // 4)))
+            except Exception as e:
+                rec["decode_gqa"] = {"error": repr(e)[:200]}
             try:
                 rec["gemm_calibration"] = bench_gemm_calibration(torch)
                 torch.cuda.empty_cache()

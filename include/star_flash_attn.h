@@ -35,8 +35,9 @@ extern "C" {
 /* Bumped whenever a struct below changes layout or an entry point changes meaning:
  *   2  kv_layout, fast_scale
  *   3  page_size / block_table / block_table_stride / num_pages / num_heads_kv appended to sfa_decode_args;
- *      a block_table entry outside the pool on the APPEND page now rejects the sequence; sfa_debug_set */
-#define SFA_ABI_VERSION 3
+ *      a block_table entry outside the pool on the APPEND page now rejects the sequence; sfa_debug_set
+ *   4  sfa_debug_get, sfa_decode_workspace_bytes_gqa added (nothing changed) */
+#define SFA_ABI_VERSION 4
 
 typedef enum sfa_status {
     SFA_OK = 0,
@@ -151,6 +152,11 @@ typedef struct sfa_decode_args {
  * sfa_decode_auto_splits(batch_size, num_heads_kv, ...) and pass that count here with num_heads. */
 size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim,
                                   int memory_max_len, int num_splits);
+/* The same for grouped queries: with num_splits <= 0 it sizes for the split count sfa_decode picks from the KV-head
+ * count.  (A workspace sized with sfa_decode_workspace_bytes(..., 0) still works: sfa_decode then takes the largest
+ * split count that fits it.) */
+size_t sfa_decode_workspace_bytes_gqa(int batch_size, int num_heads, int num_heads_kv, int head_dim,
+                                      int memory_max_len, int num_splits);
 /* The split count the library picks for num_splits <= 0; num_heads = the KV-head count. */
 int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len);
 /* Zero the sticky status word (async). Call once after allocating a workspace. */
@@ -206,6 +212,11 @@ int sfa_prefill_fwd(const sfa_prefill_args *args, void *stream);
  * csrc/prefill_dispatch.hip), "prefill_pairs" (1/2), "decode_nt" (0/1), "decode_gqa_mfma" (0/1),
  * "bm128_one_wg" (0/1).  value -1 = the library's own choice.  Process-wide. */
 int sfa_debug_set(const char *knob, int value);
+/* Read back: the knobs above, and "last_prefill_kernel" = which kernel the last sfa_prefill_fwd of this process
+ * launched (the dispatcher's choice included): 1 / 3 the 8-wave 256-row kernel (exact / prescaled), 20 + f the 128-row
+ * geometry, 40 + f the 4-wave persistent kernel (f: 1 prescaled, 2 exact), 60 / 61 the head_dim 256 kernels, -1 none
+ * yet.  Unknown knob: INT_MIN.  (bench.py names its roofline kernel from this.) */
+int sfa_debug_get(const char *knob);
 
 /* ---- small helpers the reference's C++ harness uses ----------------------------- */
 /* cos/sin LUT, [max_seq_len, rot_dim/2] each, entry (pos, j) = cos/sin(pos * 10000^(-2j/rot_dim)). */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFA_LIB_PATH") or os.path.join(_HERE, "lib", "libStarFlashAttention.so")
 
 SFA_OK = 0
-ABI_VERSION = 3          # SFA_ABI_VERSION in include/star_flash_attn.h
+ABI_VERSION = 4          # SFA_ABI_VERSION in include/star_flash_attn.h
 SFA_ERR_SEQ_LEN_RANGE = -7
 SFA_ERR_BLOCK_TABLE_RANGE = -8
 DTYPE_FP16, DTYPE_BF16 = 0, 1
@@ -19,9 +19,9 @@ DTYPE_FP16, DTYPE_BF16 = 0, 1
 # every symbol include/star_flash_attn.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "sfa_abi_version", "sfa_status_string", "sfa_last_error",
-    "sfa_decode_workspace_bytes", "sfa_decode_auto_splits", "sfa_decode_reset_status",
+    "sfa_decode_workspace_bytes", "sfa_decode_workspace_bytes_gqa", "sfa_decode_auto_splits", "sfa_decode_reset_status",
     "sfa_decode_poll_status", "sfa_decode", "sfa_prefill_fwd",
-    "sfa_compute_rotary_table", "sfa_fill_16bit", "sfa_debug_set",
+    "sfa_compute_rotary_table", "sfa_fill_16bit", "sfa_debug_set", "sfa_debug_get",
 ]
 
 
@@ -86,6 +86,8 @@ def load():
     lib.sfa_last_error.restype = ctypes.c_char_p
     lib.sfa_decode_workspace_bytes.restype = ctypes.c_size_t
     lib.sfa_decode_workspace_bytes.argtypes = [ctypes.c_int] * 5
+    lib.sfa_decode_workspace_bytes_gqa.restype = ctypes.c_size_t
+    lib.sfa_decode_workspace_bytes_gqa.argtypes = [ctypes.c_int] * 6
     lib.sfa_decode_auto_splits.restype = ctypes.c_int
     lib.sfa_decode_auto_splits.argtypes = [ctypes.c_int] * 4
     lib.sfa_decode_reset_status.restype = ctypes.c_int
@@ -107,6 +109,25 @@ def load():
         raise ImportError(f"{LIB_PATH}: ABI version {lib.sfa_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+PREFILL_KERNEL_NAMES = {1: "prefill_kernel<8 waves, 256 rows, exact>", 3: "prefill_kernel<8 waves, 256 rows, prescaled>",
+                        10: "prefill_kernel<8 waves, 256 rows, exact>", 21: "prefill_kernel_bm128<prescaled>",
+                        22: "prefill_kernel_bm128<exact>", 41: "prefill_w4_kernel<prescaled>", 42: "prefill_w4_kernel<exact>",
+                        60: "prefill_w4d_kernel<head_dim 256>", 61: "prefill_d256_kernel"}
+
+
+def debug_get(knob):
+    """sfa_debug_get: a knob's value, or "last_prefill_kernel" (the kernel the last prefill call launched)."""
+    lib = load()
+    lib.sfa_debug_get.restype = ctypes.c_int
+    lib.sfa_debug_get.argtypes = [ctypes.c_char_p]
+    return lib.sfa_debug_get(knob.encode())
+
+
+def last_prefill_kernel():
+    k = debug_get("last_prefill_kernel")
+    return PREFILL_KERNEL_NAMES.get(k, f"prefill_impl {k}")
 
 
 def debug_set(knob, value):

@@ -2,6 +2,7 @@
 // Validation + parameter marshalling only; the kernels live in decode_kernel.hip,
 // prefill_kernel.hip and aux_kernels.hip.  Nothing here allocates, copies or synchronises
 // (except sfa_decode_poll_status, which exists to do exactly that).
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -95,6 +96,17 @@ int sfa_debug_set(const char *knob, int value) {
     return SFA_OK;
 }
 
+int sfa_debug_get(const char *knob) {
+    if (!knob) return INT_MIN;
+    if (!strcmp(knob, "prefill_impl")) return g_knobs.prefill_impl.load(std::memory_order_relaxed);
+    if (!strcmp(knob, "prefill_pairs")) return g_knobs.prefill_pairs.load(std::memory_order_relaxed);
+    if (!strcmp(knob, "decode_nt")) return g_knobs.decode_nt.load(std::memory_order_relaxed);
+    if (!strcmp(knob, "decode_gqa_mfma")) return g_knobs.decode_gqa_mfma.load(std::memory_order_relaxed);
+    if (!strcmp(knob, "bm128_one_wg")) return g_knobs.bm128_one_wg.load(std::memory_order_relaxed);
+    if (!strcmp(knob, "last_prefill_kernel")) return g_knobs.last_prefill_kernel.load(std::memory_order_relaxed);
+    return INT_MIN;
+}
+
 int sfa_decode_auto_splits(int batch_size, int num_heads, int head_dim, int memory_max_len) {
     if (batch_size <= 0 || num_heads <= 0 || memory_max_len <= 0) return 1;
     return auto_splits(batch_size, num_heads, head_dim, memory_max_len);
@@ -113,6 +125,13 @@ size_t sfa_decode_workspace_bytes(int batch_size, int num_heads, int head_dim, i
     return bytes;
 }
 
+size_t sfa_decode_workspace_bytes_gqa(int batch_size, int num_heads, int num_heads_kv, int head_dim, int memory_max_len,
+                                      int num_splits) {
+    const int hkv = num_heads_kv > 0 ? num_heads_kv : num_heads;
+    const int S = num_splits > 0 ? num_splits : auto_splits(batch_size, hkv, head_dim, memory_max_len);
+    return sfa_decode_workspace_bytes(batch_size, num_heads, head_dim, memory_max_len, S);
+}
+
 int sfa_decode_reset_status(void *workspace, void *stream) {
     if (!workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode_reset_status: workspace is NULL");
     const hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, (hipStream_t)stream);
@@ -128,7 +147,8 @@ int sfa_decode_poll_status(const void *workspace, void *stream) {
     if (e != hipSuccess) return fail(SFA_ERR_LAUNCH, "sfa_decode_poll_status: %s", hipGetErrorString(e));
     if (word & 2)
         return fail(SFA_ERR_BLOCK_TABLE_RANGE,
-                    "sfa_decode: a block_table entry was outside [0, num_pages); page 0 was used in its place");
+                    "sfa_decode: a block_table entry was outside [0, num_pages); nothing was stored through it and those "
+                    "outputs are NaN");
     if (word != 0)
         return fail(SFA_ERR_SEQ_LEN_RANGE,
                     "sfa_decode: some seq_len[b] was outside [0, memory_max_len); those outputs are NaN "
@@ -190,9 +210,16 @@ int sfa_decode(const sfa_decode_args *a, void *stream) {
     if (a->batch_size == 0) return SFA_OK;
 
     // grouped queries launch one workgroup per KV head: the split count follows the kv-head count
-    const int S = a->num_splits > 0
-                      ? a->num_splits
-                      : auto_splits(a->batch_size, hkv, a->head_dim, a->memory_max_len);
+    int S = a->num_splits > 0
+                ? a->num_splits
+                : auto_splits(a->batch_size, hkv, a->head_dim, a->memory_max_len);
+    // A caller that left the choice to the library sized its workspace with sfa_decode_workspace_bytes(..., 0), which
+    // knows the query-head count only: with grouped queries the library's own choice can be larger than the one that
+    // size was computed for.  Take the largest split count the workspace holds rather than fail.
+    if (a->num_splits <= 0 && a->workspace)
+        while (S > 1 && a->workspace_bytes < sfa_decode_workspace_bytes(a->batch_size, a->num_heads, a->head_dim,
+                                                                         a->memory_max_len, S))
+            --S;
     const size_t need = sfa_decode_workspace_bytes(a->batch_size, a->num_heads, a->head_dim,
                                                    a->memory_max_len, S);
     if (!a->workspace) return fail(SFA_ERR_NULL_POINTER, "sfa_decode: workspace is NULL (need %zu bytes)", need);

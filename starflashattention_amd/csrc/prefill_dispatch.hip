@@ -27,8 +27,11 @@ namespace sfa {
 
 int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream) {
     int which = g_knobs.prefill_impl.load(std::memory_order_relaxed);
+    auto ran = [](int id) { g_knobs.last_prefill_kernel.store(id, std::memory_order_relaxed); };
+    const int flavour = p.fast_scale ? 1 : 2;       // what "by policy" resolves to (1 prescaled, 2 exact)
     if (head_dim == 256) {      // the persistent kernel; 61 forces the compiler-scheduled one (tests, A/B)
-        if (which != 61 && prefill_w4d_serves(p)) return launch_prefill_w4d(p, dtype, causal, stream);
+        if (which != 61 && prefill_w4d_serves(p)) { ran(60); return launch_prefill_w4d(p, dtype, causal, stream); }
+        ran(61);
         return launch_prefill_d256(p, dtype, causal, stream);
     }
     if (which < 0) {
@@ -58,9 +61,10 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     if (which == 0 || (which >= 30 && which <= 32) || (which >= 80 && which <= 119))
         return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d needs the A/B build of the library (build_lib(variants=True))", which);
 #endif
-    if (which >= 40 && which <= 44) return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40);
-    if (which >= 20 && which <= 22) return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20);
-    if (which >= 2) return launch_prefill_variant(which, p, dtype, head_dim, causal, stream);
+    if (which >= 40 && which <= 44) { ran(which == 40 ? 40 + flavour : which); return launch_prefill_w4(p, dtype, head_dim, causal, stream, which - 40); }
+    if (which >= 20 && which <= 22) { ran(which == 20 ? 20 + flavour : which); return launch_prefill_bm128(p, dtype, head_dim, causal, stream, which - 20); }
+    if (which >= 2) { ran(which); return launch_prefill_variant(which, p, dtype, head_dim, causal, stream); }
+    ran(p.fast_scale ? 3 : 1);
     return launch_prefill_main(p, dtype, head_dim, causal, stream);
 }
 

@@ -473,10 +473,13 @@ int launch_prefill_main(const PrefillKernelParams &p, int dtype, int head_dim, b
 // forced / diagnostic variants for the tests, tools/prefill_ab.py and tools/prefill_*stamps.py
 int launch_prefill_variant(int which, const PrefillKernelParams &p, int dtype, int head_dim, bool causal,
                            hipStream_t stream) {
+#ifdef SFA_WITH_VARIANTS      // diagnostics: the A/B library only
     if (which == 2) return launch_cfg<2, 0, 0>(p, dtype, head_dim, causal, stream);     // un-staged softmax slices
+    if (which == 4) return launch_cfg<2, 2, 2>(p, dtype, head_dim, causal, stream);     // in-kernel stamps -> lse buffer
+#endif
     if (which == 3) return launch_cfg<2, 6, 0>(p, dtype, head_dim, causal, stream);     // prescaled Q, forced
     if (which == 10) return launch_cfg<2, 2, 0>(p, dtype, head_dim, causal, stream);    // exact scale, forced
-    return launch_cfg<2, 2, 2>(p, dtype, head_dim, causal, stream);                     // in-kernel stamps -> lse buffer
+    return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d needs the A/B build of the library (build_lib(variants=True))", which);
 }
 
 }  // namespace sfa

@@ -305,13 +305,15 @@ int launch_t(const PrefillKernelParams &p_in, bool causal, int force, hipStream_
     PrefillKernelParams p = p_in;
     p.nq_tiles = (p.Sq + kBM2 - 1) / kBM2;              // 128-row q-tiles
     size_t lds = Lds<D, kBN2, 3, 2>::TOTAL;
-    if (g_knobs.bm128_one_wg.load(std::memory_order_relaxed) > 0) {     // diagnostic: one workgroup (one wave per SIMD) per CU
+#ifdef SFA_WITH_VARIANTS      // diagnostic, the A/B library only: one workgroup (one wave per SIMD) per CU
+    if (g_knobs.bm128_one_wg.load(std::memory_order_relaxed) > 0) {
         lds = 100 * 1024;
         static DynLdsAttr attr;
         if (const int rc = attr.ensure(reinterpret_cast<const void *>(&prefill_kernel_bm128<Tr, D, true, 2, 6>), (int)lds,
                                        "prefill_kernel_bm128"))
             return rc;
     }
+#endif
     dim3 grid(8u * p.bh_per_xcd * p.nq_tiles), block(kThreads2);
     // same policy as the 256-row kernel: exact scale unless the caller opted into the prescaled-Q
     // flavour (SFA_PREFILL_IMPL 21 / 22 force one or the other)

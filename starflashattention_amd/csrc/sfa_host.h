@@ -69,6 +69,7 @@ struct DebugKnobs {
     std::atomic<int> decode_nt{-1};         // decode kernels: 0 / 1 force default / non-temporal cache loads
     std::atomic<int> decode_gqa_mfma{-1};   // decode_gqa_kernel.hip: 0 forces the VALU grouped-query kernel
     std::atomic<int> bm128_one_wg{-1};      // prefill_kernel_bm128.hip: 1 = one workgroup per CU (diagnostic)
+    std::atomic<int> last_prefill_kernel{-1};   // written by launch_prefill: what ran last (sfa_debug_get)
 };
 extern DebugKnobs g_knobs;
 

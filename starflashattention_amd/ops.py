@@ -71,7 +71,7 @@ def release_workspaces():
 
 def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_len, o,
                  batch_size, memory_max_len, num_heads, head_dim, rotary_embedding_dim,
-                 max_input_length, num_layer, idx_layer, *, num_splits=0,
+                 max_input_length, num_layer, idx_layer, *, num_splits=0, _sized_by_query_heads=False,
                  rotary_cos_table=None, rotary_sin_table=None, softmax_scale=None, kv_layout="blmhd",
                  block_table=None, num_heads_kv=None):
     """One decode step (see include/star_flash_attn.h, sfa_decode).  Returns `o` (same tensor).
@@ -118,6 +118,12 @@ def flash_decode(qkv, q_bias, k_bias, v_bias, k_cache_table, v_cache_table, seq_
         # the library sizes the split count by the KV heads (one workgroup serves a whole group)
         S = int(num_splits) if num_splits and num_splits > 0 else lib.sfa_decode_auto_splits(B, Hkv, D, M)
         ws = _workspace(dev, lib.sfa_decode_workspace_bytes(B, H, D, M, S))
+        if _sized_by_query_heads:
+            # (tests) the older contract of the C ABI: a caller that leaves the split count to the library sizes its
+            # workspace with sfa_decode_workspace_bytes(..., 0), which knows the query-head count only
+            S = 0
+            ws = torch.empty(lib.sfa_decode_workspace_bytes(B, H, D, M, 0), dtype=torch.uint8, device=dev)
+            _lib.check(lib.sfa_decode_reset_status(ctypes.c_void_p(ws.data_ptr()), _stream_ptr(dev)))
         a = _lib.DecodeArgs()
         a.qkv = qkv.data_ptr()
         a.q_bias, a.k_bias, a.v_bias = (b.data_ptr() if b is not None else None for b in biases)

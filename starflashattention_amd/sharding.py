@@ -26,6 +26,17 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, dist=None, device=None):
+    """Every rank's value of one float, in rank order (one all_gather of a scalar: bench.py's per-rank times)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
 def aggregate_throughput(units_per_rank_per_step: float, steps: int, elapsed_max_s: float, world_size: int) -> float:
     """Whole-job units/s: all ranks' units divided by the slowest rank's time."""
     return world_size * units_per_rank_per_step * steps / elapsed_max_s

@@ -35,6 +35,13 @@ def test_bench_two_ranks_self_launch():
     # two ranks time-share one GPU here: the aggregate is about one GPU's rate, not two
     assert 100.0 < rec["value"] < 2 * 2500.0
     assert abs(rec["tflops_per_gpu"] * 2 - rec["value"]) < 0.02 * rec["value"]
+    # BASELINE.json configs[4]'s shard is timed on every rank as well, and every rank's time is in the line
+    c5 = rec["config5"]
+    assert c5["tflops_total"] > 100.0 and abs(c5["tflops_per_gpu"] * 2 - c5["tflops_total"]) < 0.02 * c5["tflops_total"]
+    assert abs(c5["frac_mfma_peak"] - c5["tflops_per_gpu"] / 2500.0) < 1e-3
+    assert len(rec["per_rank_ms"]["headline"]) == 2 and len(rec["per_rank_ms"]["config5"]) == 2
+    assert all(x > 0 for x in rec["per_rank_ms"]["headline"] + rec["per_rank_ms"]["config5"])
+    assert "prefill_w4_kernel" in rec["roofline"]["kernel"] and "prefill_w4_kernel" in c5["kernel"]
 
 
 def test_bench_single_rank_line():
@@ -43,3 +50,5 @@ def test_bench_single_rank_line():
     rf = rec["roofline"]
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert 100.0 < rec["value"] < 2500.0
+    assert rf["kernel"] == "prefill_w4_kernel<exact>"           # read back from the dispatcher, not a literal
+    assert len(rec["per_rank_ms"]["headline"]) == 1

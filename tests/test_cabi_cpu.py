@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
 
 
 def test_argument_validation_without_gpu(lib):
-    assert lib.sfa_abi_version() == 3
+    assert lib.sfa_abi_version() == 4
     a = _lib.DecodeArgs()
     assert lib.sfa_decode(ctypes.byref(a), None) == -1          # null pointers
     assert b"non-NULL" in lib.sfa_last_error()
@@ -111,6 +111,11 @@ def test_auto_splits_and_workspace(lib):
     assert lib.sfa_decode_workspace_bytes(256, 32, 128, 8192, 1) == 256
     assert lib.sfa_decode_workspace_bytes(2, 32, 128, 8192, 4) == 256 + 2 * 32 * 4 * 128 * 4 + 2 * 32 * 4 * 8
     assert lib.sfa_decode_workspace_bytes(2, 32, 128, 8192, 0) == lib.sfa_decode_workspace_bytes(2, 32, 128, 8192, s)
+    # grouped queries: the library sizes its split count by the KV-head count (4 here, not 32)
+    s_kv = lib.sfa_decode_auto_splits(2, 4, 128, 8192)
+    assert s_kv > s
+    assert lib.sfa_decode_workspace_bytes_gqa(2, 32, 4, 128, 8192, 0) == lib.sfa_decode_workspace_bytes(2, 32, 128, 8192, s_kv)
+    assert lib.sfa_decode_workspace_bytes_gqa(2, 32, 32, 128, 8192, 0) == lib.sfa_decode_workspace_bytes(2, 32, 128, 8192, 0)
 
 
 def test_product_never_imports_oracle():

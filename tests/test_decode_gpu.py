@@ -492,6 +492,31 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
         sfa.flash_decode(qkv, qb, kb_, vb_, kc_g, vc_g, sl, o, B, M, H, D, rot, M, L, layer, num_heads_kv=H + 1)
 
 
+def test_decode_gqa_workspace_sized_by_query_heads(sfa):
+    """The older contract of the C ABI: num_splits <= 0 and a workspace sized with sfa_decode_workspace_bytes(..., 0),
+    which knows the query-head count only.  With grouped queries the library's own split count (by KV heads) can be
+    larger than that size allows -- sfa_decode then takes the largest count that fits instead of failing (round-2
+    advisor item).  B * Hkv = 8 < 128 and M = 8192 (4 splits by KV heads, 1 by query heads): the case that used to return
+    SFA_ERR_WORKSPACE_TOO_SMALL."""
+    rng = np.random.default_rng(5)
+    B, Hkv, group, D, L, M, layer = 4, 2, 16, 128, 1, 8192, 0
+    H = Hkv * group
+    dev = torch.device("cuda:0")
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(torch.bfloat16).to(dev)
+    qkv = mk(B, H + 2 * Hkv, D)
+    kc, vc = mk(B, L, M, Hkv, D), mk(B, L, M, Hkv, D)
+    sl = torch.tensor([M - 1, 777, 0, 4099], dtype=torch.int32, device=dev)
+    o_new, o_old = (torch.empty((B, H, D), dtype=torch.bfloat16, device=dev) for _ in range(2))
+    lib = sfa._lib.load()
+    assert lib.sfa_decode_auto_splits(B, Hkv, D, M) > lib.sfa_decode_auto_splits(B, H, D, M)
+    sfa.flash_decode(qkv, None, None, None, kc.clone(), vc.clone(), sl, o_new, B, M, H, D, D, M, L, layer, num_heads_kv=Hkv)
+    sfa.flash_decode(qkv, None, None, None, kc.clone(), vc.clone(), sl, o_old, B, M, H, D, D, M, L, layer, num_heads_kv=Hkv,
+                     _sized_by_query_heads=True)
+    sfa.check_decode_status()
+    tol = TOL["bf16"]
+    np.testing.assert_allclose(o_old.float().cpu().numpy(), o_new.float().cpu().numpy(), atol=tol, rtol=tol)
+
+
 def test_decode_layouts_agree_at_scale(sfa):
     """BASELINE config 4's sequence length and head count at a batch the box can hold thrice: the
     reference layout, the head-major layout and a randomly paged pool (non-temporal loads kick in:

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from starflashattention_amd.sharding import aggregate_throughput, batch_shard, max_over_ranks
+from starflashattention_amd.sharding import aggregate_throughput, batch_shard, gather_over_ranks, max_over_ranks
 
 
 def test_batch_shard_partitions_exactly():
@@ -35,12 +35,13 @@ def _worker(rank, world, port, q):
         dist.barrier()
         elapsed = 0.010 * (rank + 1)                        # rank 1 is the slow one
         emax = max_over_ranks(elapsed, dist)
+        every = gather_over_ranks(elapsed, dist)            # bench.py's per_rank_ms
         dist.barrier()
         gathered = [torch.zeros(B * H // world if B % world == 0 else 1) for _ in range(world)]
         # verification only (not part of the product path): shards concatenate to the full result
         parts = [None] * world
         dist.all_gather_object(parts, (lo, hi, mine))
-        q.put((rank, emax, parts))
+        q.put((rank, emax, parts, every))
     finally:
         dist.destroy_process_group()
 
@@ -60,8 +61,10 @@ def test_two_rank_gloo_shards_and_max_time():
         p.join(timeout=60)
         assert p.exitcode == 0
     full = torch.arange(24, dtype=torch.float32).reshape(6, 4) * 2.0
-    for rank, emax, parts in results:
+    for rank, emax, parts, every in results:
         assert abs(emax - 0.020) < 1e-12                    # MAX over ranks, seen by every rank
+        assert every == pytest.approx([0.010, 0.020])       # every rank's own time, in rank order
         cat = torch.cat([m for _, _, m in sorted(parts, key=lambda t: t[0])])
         assert torch.equal(cat, full)
     assert aggregate_throughput(100.0, 10, 0.020, 2) == pytest.approx(100000.0)
+    assert gather_over_ranks(0.5) == [0.5]                  # no process group: the one rank's value
