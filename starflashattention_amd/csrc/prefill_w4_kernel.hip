@@ -755,17 +755,30 @@ prefill_w4_kernel(const W4Args args_by_value) {
                 dma_piece(dst + rg * L::RG + 1024 * j, (rg & 1) ? qvoff1 : qvoff0, srd, 128u * j + 16u * (rg >> 1) * rowb);
         young += 8 * NJ;
     };
-    auto fetch_q = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pieces (and whatever this wave issued since)
+    // The Q rows go from the wave's image into a[128:191] in two parts: sixteen reads, and the wait for them in front of
+    // the first MFMA that names the new rows.  A wave issues the reads as early as it can -- its last QK^T MFMA on the old
+    // rows is behind it and the image has landed: in the gaps of its last half-step that still scores (qf_hook), in an idle
+    // step behind its causal diagonal, or, failing both (q-tiles of one or two tiles, the first of the list), at the top
+    // of the next q-tile, where every wave would otherwise stand for the LDS latency of its whole image at once.
+    auto q_addr = [&](unsigned &qe, unsigned &qo) __attribute__((always_inline)) {
         const int ln = lane_now(), ql31 = ln & 31, qh2 = ln >> 5;
         const unsigned q_e = L::Q_BASE + L::RG * (ql31 >> 3) + 64 * (ql31 & 7) + 16 * (qh2 ^ ((ql31 >> 2) & 3));
-        const unsigned qe = lds0 + q_e + wave * L::TILE, qo = lds0 + (q_e ^ 32) + wave * L::TILE;
-        static_for<NQB * NKS>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, q = i / NKS, ks = i % NKS;
-            const unsigned addr = (ks & 1) ? qo : qe;
-            asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(addr), "n"(q_reg(q, ks)), "n"(q_reg(q, ks) + 3),
-                         "n"(4 * L::RG * q + 512 * (ks >> 1)) : SFA_AOWN, "memory");
-        });
+        qe = lds0 + q_e + wave * L::TILE;
+        qo = lds0 + (q_e ^ 32) + wave * L::TILE;
+    };
+    auto fetch_q_piece = [&](auto ic, unsigned qe, unsigned qo) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, q = i / NKS, ks = i % NKS;
+        const unsigned addr = (ks & 1) ? qo : qe;
+        asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(addr), "n"(q_reg(q, ks)), "n"(q_reg(q, ks) + 3),
+                     "n"(4 * L::RG * q + 512 * (ks >> 1)) : SFA_AOWN, "memory");
+    };
+    auto fetch_q_issue = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pieces (and whatever this wave issued since)
+        unsigned qe, qo;
+        q_addr(qe, qo);
+        static_for<NQB * NKS>([&](auto ic) { fetch_q_piece(ic, qe, qo); });
+    };
+    auto fetch_q_done = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: SFA_AOWN, "memory");
         if (PS) {           // prescaled flavour: fold scale * log2(e) into Q once per q-tile
             static_for<4 * NQB * NKS>([&](auto ic) {
@@ -777,6 +790,24 @@ prefill_w4_kernel(const W4Args args_by_value) {
             asm volatile("s_nop 1" ::: SFA_AOWN);   // v_accvgpr_write -> MFMA operand: two wait states
         }
     };
+    // In the gaps: gap 15 waits for the image -- the request (16 pieces) is followed by exactly the eight K/V pieces of one
+    // H2 wherever qf_on is set (see the call sites), and vmcnt retires in order -- gaps 16..31 issue one read each.  The
+    // last MFMA that read the old rows issued in gap 15 at the latest; a read's data arrives an LDS latency later.
+    bool qf_on = false;                 // wave-uniform: this half-step fetches
+    bool q_in = false;                  // the next q-tile's rows are in (or on their way into) a[128:191]
+    unsigned qf_e = 0, qf_o = 0;
+    auto qf_hook = [&](int n) __attribute__((always_inline)) {
+        if (n == 15) {
+            q_addr(qf_e, qf_o);
+            if (qf_on) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        static_for<NQB * NKS>([&](auto ic) {
+            if (n == 16 + decltype(ic)::value) {
+                if (qf_on) fetch_q_piece(ic, qf_e, qf_o);
+            }
+        });
+    };
+    auto dma_qf_hook = [&](int n) __attribute__((always_inline)) { dma_hook(n); qf_hook(n); };
 
     // ---- what a wave needs to know about its rows of a q-tile ----
     struct ItemW {
@@ -982,7 +1013,9 @@ prefill_w4_kernel(const W4Args args_by_value) {
             // (the very first time: nothing to consume, the stream's "step -1")
             // The last QK^T MFMA on the previous q-tile's Q rows is behind us: bring in this q-tile's.
             istamp(0);
-            fetch_q();
+            if (!q_in) fetch_q_issue();
+            fetch_q_done();
+            q_in = false;
             ev(5, 0);
             wait_and_sync();
             ev(2, 63);
@@ -1022,6 +1055,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
             // steps and a half to land, and the image they overwrite has just been read
             const int qreq_t = chained ? max(nt - 3, -1) : -2;
             if (qreq_t == -1) load_q(nx.b, nx.h, nx.qt);
+            const bool qf_ok = qreq_t >= 0;                 // the request is at least two barriers old where the fetch may go
             if (ntw == 0) epilogue(b, h, cw, false);        // rows that see no key at all
 
             // A wave's steps of a q-tile come in three phases -- full steps, its last tile, idle steps behind its causal
@@ -1075,15 +1109,19 @@ prefill_w4_kernel(const W4Args args_by_value) {
                         ev(3, t);
                         step_done();
                     }
+                    qf_on = qf_ok && ntw == nt;             // (behind the request: H1(nt-2), H2(nt-2) with its eight pieces)
                     hstep<Tr, D, ORD, 0, 0, 1, 1, PS ? 1 : 3>(lds, k_e, v_e, vcur, ring_next(kcur), sB, sA, acc, fin, pend, c2,
-                                                               3, t * kKeys + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
+                                                               3, t * kKeys + 32, cw.qbase, cw.klast, diag0, ninf16, kpre, qf_hook);
+                    if (qf_on) { q_in = true; qf_on = false; }
                     ev(1, t);
                 } else {
                     for (;;) {
                         const int k1 = ring_next(kcur);
                         const int kbase = t * kKeys;
+                        qf_on = qf_ok && ntw == nt && t + 1 == nt;
                         hstep<Tr, D, ORD, 0, 0, 1, 1, 1>(lds, k_e, v_e, vcur, k1, sB, sA, acc, fin, pend, c2,
-                                                          mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, diag0, ninf16, kpre);
+                                                          mask_bits(cw, kbase + 32), kbase + 32, cw.qbase, cw.klast, diag0, ninf16, kpre, qf_hook);
+                        if (qf_on) { q_in = true; qf_on = false; }
                         ev(1, t);
                         if (t + 1 == ntw) break;            // the wave's last tile: its second half is the seam's, or ends the q-tile
                         wait_and_sync();
@@ -1097,8 +1135,10 @@ prefill_w4_kernel(const W4Args args_by_value) {
                 if (!full_wave) {
                     wait_and_sync();
                     ev(2, t);
+                    qf_on = qf_ok && ntw + 1 == nt;         // (this is H2(nt-2): the request, H1(nt-2), this half-step's pieces)
                     hstep<Tr, D, ORD, 1, 1, 0, 1, 1>(lds, k_e, v_e, vcur, ring_next(kcur), sA, sB, acc, fin, pend, c2,
-                                                         0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
+                                                         0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_qf_hook);
+                    if (qf_on) { q_in = true; qf_on = false; }
                     ev(3, t);
                     // this wave's rows are stored in the time it would otherwise idle: one block now (the working waves
                     // reach the next barrier one half-step from here), the other in the next step -- an idle one, or the
@@ -1118,6 +1158,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
                     produce_k();
                     ev(3, t);
                     if (epi_pending) { epilogue_q(b, h, cw, 1, true); epi_pending = false; ev(4, t); }
+                    if (qf_ok && t == nt - 2) { fetch_q_issue(); q_in = true; }     // (requested behind step nt-3)
                     step_done();
                 }
             }

@@ -453,8 +453,17 @@ def test_decode_grouped_queries(sfa, dtype, D, group, num_splits):
     ref = decode_ref(f(qkv_x), f(rep(kc, 3)), f(rep(vc, 3)), lens, layer, rot, dtype=dtype, q_bias=f(qb),
                      k_bias=f(rep(kb_, 0)), v_bias=f(rep(vb_, 0)))
     np.testing.assert_allclose(f(o), ref["o"], atol=tol, rtol=tol)         # the fp64 oracle on the expanded problem
-    if group == 2 and D == 128:     # same row grouping as the multi-head kernel: bit-identical
-        assert torch.equal(o, o_x)
+    if group == 2:
+        # Same row grouping as the multi-head kernel (four row groups a step, the same lane groups, the same split
+        # merge): bit-identical -- measured on MI355X for every (dtype, head_dim) here but fp16 at head_dim 256, where
+        # isolated elements differ by ONE fp16 ulp (max |diff| 1.5e-5 at all three num_splits; bf16 at 256 is identical,
+        # its ulp being 8 x coarser).  The two kernels' source arithmetic is the same; the cause was not isolated further
+        # (hipcc contracting a multiply-add differently in one of the two instantiations is the candidate).
+        if (dtype, D) == ("fp16", 256):
+            ulps = (o.view(torch.int16).int() - o_x.view(torch.int16).int()).abs()
+            assert int(ulps.max()) <= 1
+        else:
+            assert torch.equal(o, o_x)
     # appended rows: identical to the expanded run's, everything else untouched
     assert torch.equal(rep(kc_g, 3), kc_x) and torch.equal(rep(vc_g, 3), vc_x)
     mask = torch.ones((B, L, M), dtype=torch.bool, device=dev)

@@ -5,6 +5,7 @@ counts 64 B per 128-B request for wide coalesced reads, so it is doubled here
 (MI355X_MICROARCH.md, HBM section)."""
 import csv, glob, os, sys, collections
 root = sys.argv[1]
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # warm-up launches of each kernel to leave out of the timed statistics
 def short(n):
     n = n.replace("void ", "").replace("sfa::(anonymous namespace)::", "").replace("sfa::", "")
     return n.split("(")[0][:70]
@@ -14,6 +15,22 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
         if "sfa::" in row["Name"]:
             print(f"  {short(row['Name']):70s} calls={row['Calls']:>3s} avg={float(row['AverageNs'])/1e6:8.4f} ms "
                   f"min={float(row['MinNs'])/1e6:8.4f} max={float(row['MaxNs'])/1e6:8.4f}")
+# the same from the per-dispatch trace, WITHOUT each kernel's first `skip` launches (bench.py's warm-up steps: the first
+# launches after start-up run slower and are not part of the timed region)
+if skip:
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        per = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "sfa::" in row["Kernel_Name"]:
+                per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        if not per:
+            continue
+        print(f"== timed launches only: each kernel's first {skip} launches (warm-up) dropped (", os.path.relpath(f, root), ")")
+        for k, v in per.items():
+            v.sort()
+            d = [(e - s) / 1e6 for s, e in v[skip:]]
+            if d:
+                print(f"  {k:70s} calls={len(d):>3d} avg={sum(d)/len(d):8.4f} ms min={min(d):8.4f} max={max(d):8.4f}")
 tot = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
