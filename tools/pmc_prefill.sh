@@ -3,7 +3,7 @@
 # runs, no trace domains besides kernel-trace (gpurun refuses other combinations).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-OUT=$PWD/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
+OUT=$PWD/gpurun_out/${PMC_OUT:-pmc}; rm -rf $OUT; mkdir -p $OUT     # (SHAPE=B,H,S CAUSAL=0/1 HD IMPL: tools/prefill_once.py)
 export IMPL=${IMPL:--1}      # tools/prefill_once.py passes it to sfa_debug_set("prefill_impl", ...)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters.txt 2>&1 < /dev/null
