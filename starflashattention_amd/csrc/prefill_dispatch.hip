@@ -37,12 +37,17 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
     if (which < 0) {
         const long long nq = (p.Sq + 255) / 256;
         const long long qtiles = (long long)p.B * p.Hq * nq;
-        // Measured crossover of the 4-wave persistent kernel against the best of the other two
-        // (tools/prefill_crossover.sh): full attention from 256 q-tiles on (+5..20 %); under the causal
-        // mask only long rows pay -- 16 q-tiles per head and 2048 in all, or 32 per head and 1024 in all
-        // (+2..5 %; at seqlen 2048 and below its per-q-tile fixed costs lose 5..15 %).
-        const bool w4 = prefill_w4_serves(p, head_dim) && (causal ? ((nq >= 16 && qtiles >= 2048) || (nq >= 32 && qtiles >= 1024))
-                                                   : qtiles >= kW4MinTiles);
+        // Measured crossover of the 4-wave persistent kernel against the best of the other two (tools/prefill_crossover.sh,
+        // round 3's kernel, profiles/r03_prefill_crossover.txt).  Full attention: from 256 q-tiles on (+10..25 %; 128: -3 %),
+        // whatever the key count (8 x 32 x 4096 queries against 64 .. 1024 keys: +16..25 %).  Under the causal mask its
+        // per-q-tile fixed costs weigh more on short rows: 16+ q-tiles per head from 256 q-tiles on (+2..7 %), 8 per head from
+        // 1024 (512: -2 %, 2048: +8 %), 4 per head (seqlen 1024) from 2048 (+2 %; 4096: +11 %).  Fewer keys than queries
+        // under the (bottom-right aligned) causal mask leaves q-tiles with few or no keys -- 8 x 32 x 4096 against 1024 keys
+        // -20 %, against 2048 -6 % -- so those go to the other kernels.
+        const bool w4_pays = !causal ? qtiles >= kW4MinTiles
+                           : p.Sk < p.Sq ? false
+                           : nq >= 16 ? qtiles >= 256 : nq >= 8 ? qtiles >= 1024 : nq >= 4 ? qtiles >= 2048 : false;
+        const bool w4 = w4_pays && prefill_w4_serves(p, head_dim);
         if (w4) {
             which = 40;
         } else {

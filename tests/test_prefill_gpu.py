@@ -192,6 +192,33 @@ def test_prefill_auto_falls_back_when_a_head_spans_2gib(sfa):
     del kbase, k
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,causal,w4", [
+    (2, 32, 4096, 4096, True, True),        # 1024 q-tiles, 16 per head: +6 % (profiles/r03_prefill_crossover.txt)
+    (8, 32, 2048, 2048, True, True),        # 2048 q-tiles, 8 per head: +8 %
+    (2, 32, 2048, 2048, True, False),       # 512 q-tiles, 8 per head: -2 %
+    (16, 32, 1024, 1024, True, True),       # 2048 q-tiles, 4 per head: +2 %
+    (8, 32, 4096, 1024, True, False),       # fewer keys than queries under the causal mask: -20 %
+    (8, 32, 4096, 8192, True, True),
+    (8, 32, 4096, 64, False, True),         # full attention: any key count from 256 q-tiles on
+    (1, 8, 4096, 4096, False, False),       # 128 q-tiles
+])
+def test_prefill_auto_rule_follows_the_measured_crossover(sfa, B, H, Sq, Sk, causal, w4):
+    """The dispatcher's choice (read back through sfa_debug_get("last_prefill_kernel")) at the shapes the crossover
+    table was measured on, and the chosen kernel's output against a forced other geometry."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    q = torch.randn((B, H, Sq, 128), generator=g, device=dev).bfloat16()
+    k, v = (torch.randn((B, H, Sk, 128), generator=g, device=dev).bfloat16() for _ in range(2))
+    o = sfa.flash_attn_fwd(q, k, v, causal=causal)
+    assert ("prefill_w4_kernel" in sfa.last_prefill_kernel()) == w4, sfa.last_prefill_kernel()
+    sfa.debug_set("prefill_impl", 22 if w4 else 42)
+    try:
+        o2 = sfa.flash_attn_fwd(q, k, v, causal=causal)
+    finally:
+        sfa.debug_set("prefill_impl", -1)
+    np.testing.assert_allclose(o.float().cpu().numpy(), o2.float().cpu().numpy(), atol=8e-3, rtol=8e-3)
+
+
 NON_BASELINE = [(i, 128) for i in IMPLS if i not in ("auto", "d256_fallback")] + [("auto", 256), ("d256_fallback", 256)]
 
 

@@ -16,14 +16,21 @@ B, H, S = 16, 32, 4096
 for a in sys.argv[1:]:
     if a.startswith("--shape="):          # --shape=B,H,S
         B, H, S = (int(x) for x in a.split("=")[1].split(","))
+Sk = S
+for a in sys.argv[1:]:
+    if a.startswith("--sk="):             # keys per sequence when it is not the query count (causal: the mask is bottom-right aligned)
+        Sk = int(a.split("=")[1])
 fp16 = "--fp16" in sys.argv
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
-q, k, v = (torch.randn((B, H, S, D), generator=g, device=dev).to(torch.float16 if fp16 else torch.bfloat16) for _ in range(3))
+q, k, v = (torch.randn((B, H, n, D), generator=g, device=dev).to(torch.float16 if fp16 else torch.bfloat16) for n in (S, Sk, Sk))
 if "--kvshared" in sys.argv:       # every (batch, head) reads the SAME K/V (stride 0): all re-reads hit L2
-    k, v = k[:1, :1].expand(B, H, S, D), v[:1, :1].expand(B, H, S, D)
+    k, v = k[:1, :1].expand(B, H, Sk, D), v[:1, :1].expand(B, H, Sk, D)
 outs = {}
 flops = 4.0 * B * H * S * S * D / (2 if causal else 1)
+if Sk != S:                               # visible (query, key) pairs: row i sees keys 0 .. i + Sk - S
+    vis = sum(min(Sk, max(0, i + Sk - S + 1)) for i in range(S)) if causal else S * Sk
+    flops = 4.0 * B * H * vis * D
 def run(impl, n):
     sfa.debug_set("prefill_impl", impl)
     o = torch.empty_like(q)
@@ -44,4 +51,4 @@ ref = outs[impls[0]].float()
 for i in impls:
     ms = sorted(res[i]); med = ms[len(ms)//2]
     err = (outs[i].float() - ref).abs().max().item()
-    print(f"[B={B} H={H} S={S} D={D} {'fp16' if fp16 else 'bf16'} {'causal' if causal else 'full'}] impl {i}: median {med:.3f} ms  min {ms[0]:.3f} ms  {flops/med/1e9:.1f} TFLOPS (best {flops/ms[0]/1e9:.1f})  max|diff vs impl {impls[0]}| = {err:.4g}", flush=True)
+    print(f"[B={B} H={H} S={S}{'' if Sk == S else f' Sk={Sk}'} D={D} {'fp16' if fp16 else 'bf16'} {'causal' if causal else 'full'}] impl {i}: median {med:.3f} ms  min {ms[0]:.3f} ms  {flops/med/1e9:.1f} TFLOPS (best {flops/ms[0]/1e9:.1f})  max|diff vs impl {impls[0]}| = {err:.4g}", flush=True)
