@@ -48,6 +48,7 @@ namespace {
 using namespace prefill;
 
 namespace w4 {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 using namespace w4c;
 
@@ -819,10 +820,8 @@ prefill_w4_kernel(const W4Args args_by_value) {
         int t_mask;         // first step whose half-steps score keys that may need masking (those of tiles t_mask .. )
         int aligned;        // the wave's last tile is a whole 64 x 64 corner on the causal diagonal (and not its first tile)
     };
-    auto item_w = [&](int qt, int nt, ItemW &w) __attribute__((always_inline)) {
-        const ArgPtr a = arg();
-        const int coff = a->cur.coff, Sk = a->cur.Sk;       // causal: key j visible iff j <= i + coff
-        w.wq0 = qt * kRows + 64 * wave;
+    auto item_w_of = [&](int wv, int coff, int Sk, int qt, int nt, ItemW &w) __attribute__((always_inline)) {
+        w.wq0 = qt * kRows + 64 * wv;                       // causal: key j visible iff j <= i + coff
         w.qbase = CAUSAL ? w.wq0 + coff : (1 << 29);
         w.klast = Sk - 1;
         w.ntw = nt;
@@ -920,13 +919,16 @@ prefill_w4_kernel(const W4Args args_by_value) {
     // ~1.8 k cycles of VALU issue per block (64 accumulator reads, 64 multiplies, 32 converts, 16 half swaps, 8 stores):
     // a wave that finishes a q-tile early stores one block behind its last half-step and the other one step later,
     // so that it is never late at a barrier the working waves are waiting at.
-    auto epilogue_q = [&](int b, int h, const ItemW &w, int q, bool have_o) __attribute__((always_inline)) {
+    struct EpiArgs { int Sq; uint16_t *obase; long long os2; float *lse_p; long long lse_row0; };
+    auto load_epi = [&](int b, int h) __attribute__((always_inline)) -> EpiArgs {        // one burst of scalar loads per epilogue
         const ArgPtr a = arg();
         const int Sq = a->Sq;
-        uint16_t *const obase = a->o + b * a->os0 + h * a->os1;
-        const long long os2 = a->os2;
-        float *const lse_p = a->lse;
-        const long long lse_row0 = ((long long)b * a->cur.Hq + h) * Sq;
+        return EpiArgs{Sq, a->o + b * a->os0 + h * a->os1, a->os2, a->lse, ((long long)b * a->cur.Hq + h) * Sq};
+    };
+    auto epilogue_q = [&](const EpiArgs &ea, const ItemW &w, int q, bool have_o) __attribute__((always_inline)) {
+        const int Sq = ea.Sq;
+        const long long os2 = ea.os2;
+        float *const lse_p = ea.lse_p;
         const int ln = lane_now(), l31 = ln & 31, h2 = ln >> 5;
         const int qrow = w.wq0 + 32 * q + l31;
         float ltot = 0.f;
@@ -935,20 +937,28 @@ prefill_w4_kernel(const W4Args args_by_value) {
             ltot = half_sum(fin.lsum[q]);
         }
         const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+        f32x2 inv2;
+        inv2[0] = inv; inv2[1] = inv;
         if (qrow < Sq) {
-            uint16_t *orow = obase + (long long)qrow * os2;
+            uint16_t *orow = ea.obase + (long long)qrow * os2;
             if (have_o) {
                 static_for<2 * NDB>([&](auto ic) {
                     constexpr int d = decltype(ic)::value >> 1, g = 2 * (decltype(ic)::value & 1);
-                    auto rd = [&](auto rc) __attribute__((always_inline)) -> float {
+                    // two accumulator registers -> one register pair -> v_pk_mul_f32 (no MFMA runs beside the epilogue, so the
+                    // packed op issues at once: tools/micro/pk_f32.hip) -> one v_cvt_pk
+                    auto rd2 = [&](auto rc) __attribute__((always_inline)) -> uint32_t {
                         constexpr int r = decltype(rc)::value;
-                        return (q == 0 ? own_read<o_reg(0, d) + r>() : own_read<o_reg(1, d) + r>()) * inv;
+                        f32x2 pr;
+                        pr[0] = q == 0 ? own_read<o_reg(0, d) + r>() : own_read<o_reg(1, d) + r>();
+                        pr[1] = q == 0 ? own_read<o_reg(0, d) + r + 1>() : own_read<o_reg(1, d) + r + 1>();
+                        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pr) : "v"(inv2));
+                        return Tr::pack2(pr[0], pr[1]);
                     };
                     using std::integral_constant;
-                    const uint32_t ax = Tr::pack2(rd(integral_constant<int, 4 * g + 0>{}), rd(integral_constant<int, 4 * g + 1>{}));
-                    const uint32_t ay = Tr::pack2(rd(integral_constant<int, 4 * g + 2>{}), rd(integral_constant<int, 4 * g + 3>{}));
-                    const uint32_t bx = Tr::pack2(rd(integral_constant<int, 4 * g + 4>{}), rd(integral_constant<int, 4 * g + 5>{}));
-                    const uint32_t by = Tr::pack2(rd(integral_constant<int, 4 * g + 6>{}), rd(integral_constant<int, 4 * g + 7>{}));
+                    const uint32_t ax = rd2(integral_constant<int, 4 * g + 0>{});
+                    const uint32_t ay = rd2(integral_constant<int, 4 * g + 2>{});
+                    const uint32_t bx = rd2(integral_constant<int, 4 * g + 4>{});
+                    const uint32_t by = rd2(integral_constant<int, 4 * g + 6>{});
                     const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                     // lower lanes: [own g | upper's g] = columns 8g..8g+7; upper lanes: [lower's g+1 | own g+1]
@@ -963,7 +973,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
             }
             if (!(DIAG & 257) && lse_p && h2 == 0) {
                 const float lse = ltot > 0.f ? (fin.msc[q] + __log2f(ltot)) * kLn2 : ninf();
-                lse_p[lse_row0 + qrow] = lse;
+                lse_p[ea.lse_row0 + qrow] = lse;
             }
         }
         if (have_o) {               // the block's O starts the next q-tile from zero (all lanes: outside the row predicate)
@@ -977,8 +987,9 @@ prefill_w4_kernel(const W4Args args_by_value) {
         if (w.wq0 + 32 * q + 31 < Sq) young += 8;           // every lane stored: 8 row stores at least
     };
     auto epilogue = [&](int b, int h, const ItemW &w, bool have_o) __attribute__((always_inline)) {
-        epilogue_q(b, h, w, 0, have_o);
-        epilogue_q(b, h, w, 1, have_o);
+        const EpiArgs ea = load_epi(b, h);
+        epilogue_q(ea, w, 0, have_o);
+        epilogue_q(ea, w, 1, have_o);
     };
     // q-tiles without any key (causal rows in front of the first key; Sq > Sk only): O = 0, lse = -inf.  They own no
     // stream position, so they are dealt with up front; the pipeline below walks the q-tiles that have keys.
@@ -988,7 +999,8 @@ prefill_w4_kernel(const W4Args args_by_value) {
         while (c0.live) {
             if (c0.nt == 0) {
                 ItemW w0;
-                item_w(c0.qt, 0, w0);
+                const ArgPtr a0 = arg();
+                item_w_of(wave, a0->cur.coff, a0->cur.Sk, c0.qt, 0, w0);
                 epilogue(c0.b, c0.h, w0, false);
             }
             next_item(c0, false);
@@ -1008,7 +1020,10 @@ prefill_w4_kernel(const W4Args args_by_value) {
         ItemW cw;                                           // this wave's view of the current q-tile
         bool full_wave;
         for (;;) {
-            item_w(cc.qt, cc.nt, cw);
+            {
+                const ArgPtr a = arg();
+                item_w_of(wave, a->cur.coff, a->cur.Sk, cc.qt, cc.nt, cw);
+            }
             // ======== the second half of the previous q-tile's last step, which scores this q-tile's first half-tile ========
             // (the very first time: nothing to consume, the stream's "step -1")
             // The last QK^T MFMA on the previous q-tile's Q rows is behind us: bring in this q-tile's.
@@ -1038,7 +1053,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
                     hstep<Tr, D, ORD, 1, 1, 2, 0, 1>(lds, k_e, v_e, vcur, k1, sA, sB, acc, fin, pend, c2,
                                                           mask_bits(cw, 0), 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
                     ev(3, 63);
-                    if (epi_pending) { epilogue_q(pb, ph, pw, 1, true); epi_pending = false; ev(4, 63); }
+                    if (epi_pending) { epilogue_q(load_epi(pb, ph), pw, 1, true); epi_pending = false; ev(4, 63); }
                 }
                 kcur = k1;
                 vcur = ring_next(vcur);
@@ -1143,7 +1158,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
                     // this wave's rows are stored in the time it would otherwise idle: one block now (the working waves
                     // reach the next barrier one half-step from here), the other in the next step -- an idle one, or the
                     // half-step that joins the next q-tile while the wave that owns the diagonal's end runs its own epilogue
-                    epilogue_q(b, h, cw, 0, true);
+                    epilogue_q(load_epi(b, h), cw, 0, true);
                     ev(4, t);
                     epi_pending = true;
                     step_done();
@@ -1157,7 +1172,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
                     produce_v();
                     produce_k();
                     ev(3, t);
-                    if (epi_pending) { epilogue_q(b, h, cw, 1, true); epi_pending = false; ev(4, t); }
+                    if (epi_pending) { epilogue_q(load_epi(b, h), cw, 1, true); epi_pending = false; ev(4, t); }
                     if (qf_ok && t == nt - 2) { fetch_q_issue(); q_in = true; }     // (requested behind step nt-3)
                     step_done();
                 }
@@ -1177,7 +1192,7 @@ prefill_w4_kernel(const W4Args args_by_value) {
                                                   0, 0, cw.qbase, cw.klast, diag0, ninf16, kpre, dma_hook);
             epilogue(cc.b, cc.h, cw, true);
         } else if (epi_pending) {
-            epilogue_q(cc.b, cc.h, cw, 1, true);
+            epilogue_q(load_epi(cc.b, cc.h), cw, 1, true);
         }
     }
     // drain: the last steps' pieces must have landed before the workgroup's LDS is released
