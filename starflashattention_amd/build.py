@@ -83,11 +83,22 @@ def build_lib(force=False, verbose=False, extra_flags=(), variants=False):
         return out
     cc = hipcc()
 
+    hdrs = _headers()
+
     def compile_one(src):
+        # an object is rebuilt only when its source, a header or its flags changed (the 4-wave prefill kernels take
+        # minutes each; a one-line change elsewhere should not recompile them)
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        log = _run([cc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
+        mine = flags + EXTRA_FLAGS.get(os.path.basename(src), [])
+        ostamp = _stamp([src] + hdrs, " ".join(mine))
+        ostamp_file = obj + ".stamp"
+        if (not force and os.path.exists(obj) and os.path.exists(ostamp_file) and open(ostamp_file).read() == ostamp):
+            return obj
+        log = _run([cc] + mine + ["-c", src, "-o", obj])
         if verbose and log.strip():
             print(log)
+        with open(ostamp_file, "w") as f:
+            f.write(ostamp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:

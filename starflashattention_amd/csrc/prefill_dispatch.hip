@@ -59,6 +59,14 @@ int launch_prefill(const PrefillKernelParams &p, int dtype, int head_dim, bool c
         }
     }
 #ifdef SFA_WITH_VARIANTS
+    // the stamping / event-log builds (A/B library only) write up to 4 x 512 u64 into the caller's lse buffer instead of the lse
+    {
+        const int f = which >= 80 ? which - 80 : which - 40;
+        const bool stamps = which >= 80 ? (which < 120 && (f == 4 || (f >= 16 && f <= 19) || f >= 21))     // round 2's kernel
+                                        : (which == 43 || which == 44);
+        if (stamps && (!p.lse || (long long)p.B * p.Hq * p.Sq * (long long)sizeof(float) < 4 * 512 * 8))
+            return fail(SFA_ERR_BAD_SHAPE, "prefill_impl %d is a stamping build: it needs an lse buffer of at least 16 KiB", which);
+    }
     if (which == 0) return launch_prefill_baseline(p, dtype, head_dim, causal, stream);
     if (which >= 30 && which <= 32) return launch_prefill_x16(p, dtype, head_dim, causal, stream, which - 30);
     if (which >= 80 && which <= 119) return launch_prefill_w4r2(p, dtype, head_dim, causal, stream, which - 80);

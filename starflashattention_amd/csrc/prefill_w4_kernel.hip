@@ -1254,6 +1254,7 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     if (!prefill_w4_serves(p, head_dim))
         return fail(SFA_ERR_BAD_SHAPE, "sfa_prefill_fwd: one head's Q/K/V rows span more than 2 GiB");
     const bool prescaled = force == 0 ? p.fast_scale != 0 : force == 1;
+    (void)prescaled;
 #ifdef SFA_WITH_VARIANTS        // the q-tile stamping build (tools/w4_item_stamps.py): the A/B library only
     if (force == 3) return launch_w4_t<Bf16, 128, 2, 256>(p, causal, stream);
     if (force == 4) return launch_w4_t<Bf16, 128, 2, 1>(p, causal, stream);         // the event log (tools/w4_events.py)
