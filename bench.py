@@ -222,6 +222,41 @@ def bench_gemm_calibration(torch):
             "note": "library GEMM on the same device and data distribution: the power-capped MFMA rate, not a target"}
 
 
+def measure_traffic(timeout_s=150):
+    """--measure-traffic: HBM bytes per launch of the headline kernel, measured NOW -- two rocprofv3 child processes
+    (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) over tools/prefill_once.py, which
+    launches the same kernel on the same shape.  Children, never an exec; counters with --kernel-trace only.  Returns
+    (bytes, source) or (None, reason).  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="sfa_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", N="6")
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                                sys.executable, os.path.join(ROOT, "tools", "prefill_once.py")],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "prefill_w4_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for the prefill kernel"
+            vals[counter] = sum(got[1:]) / max(1, len(got) - 1) if len(got) > 1 else got[0]     # first launch: cold
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    total = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return total, "measured in this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over tools/prefill_once.py (same kernel, same shape), per launch"
+
+
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: start N fresh ranks (torch.distributed.run) and relay their output.
     Nothing in THIS process has touched a GPU yet (torch is not even imported), and it is never replaced by
@@ -244,6 +279,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] shard under --gpus N > 1")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="measure roofline.traffic now (two rocprofv3 --pmc child runs, ~40 s) instead of citing profiles/")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -329,6 +366,15 @@ def main():
                 break
             except Exception:
                 pass
+        if args.measure_traffic and world == 1:
+            try:
+                t_now, why = measure_traffic()
+            except Exception as e:
+                t_now, why = None, repr(e)[:200]
+            if t_now is not None:
+                traffic, traffic_src = t_now, why
+            else:
+                traffic_src = f"{traffic_src}; --measure-traffic failed: {why}"
         rec = {
             "metric": "attention fwd TFLOPS/GPU (% MFMA peak), bf16 seqlen=4096 hdim=128",
             "value": round(total_tflops, 2), "unit": "TFLOPS",

@@ -52,3 +52,15 @@ def test_bench_single_rank_line():
     assert 100.0 < rec["value"] < 2500.0
     assert rf["kernel"] == "prefill_w4_kernel<exact>"           # read back from the dispatcher, not a literal
     assert len(rec["per_rank_ms"]["headline"]) == 1
+
+
+def test_bench_measures_traffic_live():
+    """--measure-traffic: roofline.traffic comes from rocprofv3 --pmc child runs of this very invocation, not from profiles/.
+    Q + K + V + O of the headline shape are 2.147e9 B; the kernel re-reads part of K / V (2.9-3.1e9 measured)."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    rec = run_bench("--measure-traffic")
+    rf = rec["roofline"]
+    assert "measured in this run" in rf["traffic_source"], rf["traffic_source"]
+    assert 2.147e9 <= rf["traffic"] < 4.5e9
