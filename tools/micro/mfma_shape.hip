@@ -4,7 +4,9 @@
 // that cycles therefore do not decide.  Here the two shapes carry the REAL filler mix of prefill_w4_kernel.hip per
 // 32768 FLOP of matrix work (one 32x32x16 or two 16x16x32): v_fma (SGPR operand) + v_exp + v_add + every second slot a
 // v_cvt_pk + half a v_max3, one ds_read_b128 of a random-data LDS image per slot (consumed eight slots later), one wave
-// per SIMD, every CU busy.  Reported: cycles per slot, the clock the chip held (s_memtime / s_memrealtime) and the
+// per SIMD, every CU busy; a fragment is read 16 slots ahead of its MFMA and the wave waits once per batch of eight,
+// for a read issued nine slots earlier (as in the kernel: every LDS read >= 8 gaps ahead, one s_waitcnt per batch).
+// Reported: cycles per slot, the clock the chip held (s_memtime / s_memrealtime) and the
 // wall time per slot -- all three (cdna_hip_programming.md rule 28).
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_shape.hip -o build/mfma_shape && build/mfma_shape
 #include <hip/hip_runtime.h>
@@ -38,28 +40,29 @@ __global__ void __launch_bounds__(256, 1) k(const unsigned *in, float *out, unsi
     for (int i = 0; i < 32; ++i) x[i] = 0.001f * (lane + i);
     float lsum = 0.f, ms = 0.5f, mx = 0.f;
     unsigned pk[8] = {};
-    u32x4 kf[8];
-    for (int i = 0; i < 8; ++i) kf[i] = *reinterpret_cast<lds_u4 *>(lp + 1024 * (i & 3));
+    u32x4 kf[16];
+    for (int i = 0; i < 16; ++i) kf[i] = *reinterpret_cast<lds_u4 *>(lp + 1024 * (i & 3));
     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 8");
     unsigned long long t0, r0, t1, r1;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (g == 0 || g == 8) asm volatile("" :: "v"(kf[(g + 7) & 7]));     // one wait per batch of eight fragments
+            if (g == 0 || g == 8) asm volatile("" :: "v"(kf[g + 7]));           // one wait per batch of eight fragments: the youngest
+                                                                                // of them was read nine slots ago
             if (SHAPE == 32) {
-                if ((g >> 3) & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s1) : "v"(kf[g & 7]), "v"(b1));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s0) : "v"(kf[g & 7]), "v"(b0));
+                if ((g >> 3) & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s1) : "v"(kf[g]), "v"(b1));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s0) : "v"(kf[g]), "v"(b0));
             } else {
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t[(2 * g) & 7]) : "v"(kf[g & 7]), "v"(b0));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t[(2 * g) & 7]) : "v"(kf[g]), "v"(b0));
             }
             if (FILL) {
                 asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(x[(g + 2) & 31]) : "s"(c2), "v"(ms));
                 asm volatile("v_exp_f32_e32 %0, %0" : "+v"(x[(g + 1) & 31]));
             }
-            if (SHAPE == 16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t[(2 * g + 1) & 7]) : "v"(kf[g & 7]), "v"(b1));
-            // the slot's LDS read: the fragment consumed eight slots later (behind the slot's last MFMA that reads the old one)
-            *(u32x4 *)&kf[g & 7] = *reinterpret_cast<lds_u4 *>(lp + 1024 * ((g * 5 + it) & 3) + 16384 * (g & 1));
+            if (SHAPE == 16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t[(2 * g + 1) & 7]) : "v"(kf[g]), "v"(b1));
+            // the slot's LDS read: the fragment consumed sixteen slots later (behind the slot's last MFMA that reads the old one)
+            *(u32x4 *)&kf[g] = *reinterpret_cast<lds_u4 *>(lp + 1024 * ((g * 5 + it) & 3) + 16384 * (g & 1));
             if (FILL) {
                 asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(lsum) : "v"(x[g & 31]));
                 if (g & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(g >> 1) & 7]) : "v"(x[(g - 1) & 31]), "v"(x[g & 31]));

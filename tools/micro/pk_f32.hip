@@ -72,6 +72,30 @@ __global__ void __launch_bounds__(256, 1) k(const bf16x8 *in, float *out, unsign
                     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(g >> 1) & 7]) : "v"(x[g & 15][0]), "v"(x[g & 15][1]));
                     asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(lsum[0]) : "s"(0x3f803f80u), "v"(pk[((g >> 1) + 7) & 7]));
                 }
+            } else if (MODE == 10) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(EL));
+            } else if (MODE == 11) {
+                asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(EL));
+            } else if (MODE == 12) {
+                asm volatile("v_exp_f16 %0, %0" : "+v"(EL));
+            } else if (MODE == 13) {        // the shipped gap on the legacy exponential
+                asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(x[(g + 5) & 15][g & 1]) : "s"(c2), "v"(ms[0]));
+                asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(EL));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(lsum[0]) : "v"(x[(g + 1) & 15][g & 1]));
+                if (g & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[(g >> 1) & 7]) : "v"(x[g & 15][0]), "v"(x[g & 15][1]));
+            } else if (MODE == 14) {        // 16-bit exponential: fma -> f16 (v_fma_mixlo_f16), v_exp_f16, row sum by v_fma_mix_f32
+                asm volatile("v_fma_mixlo_f16 %0, %0, %1, -%2" : "+v"(x[(g + 5) & 15][g & 1]) : "s"(c2), "v"(ms[0]));
+                asm volatile("v_exp_f16 %0, %0" : "+v"(EL));
+                asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(lsum[0]) : "v"(x[(g + 1) & 15][g & 1]));
+            } else if (MODE == 15) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(EL));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(x[(g + 7) & 15][g & 1]));
+            } else if (MODE == 16) {
+                asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(EL));
+                asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(x[(g + 7) & 15][g & 1]));
+            } else if (MODE == 17) {
+                asm volatile("v_exp_f16 %0, %0" : "+v"(EL));
+                asm volatile("v_exp_f16 %0, %0" : "+v"(x[(g + 7) & 15][g & 1]));
             }
             FENCE();
         }
@@ -113,5 +137,13 @@ int main() {
     BOTH(1, "packed gap: even pk_fma + exp, odd exp + pk_add + cvt_pk")
     BOTH(8, "1 v_dot2c_f32_bf16 (SGPR ones, packed pair)")
     BOTH(9, "dot2 gap: fma + exp (+ cvt_pk + dot2c / 2)")
+    BOTH(10, "1 v_exp_f32")
+    BOTH(15, "2 v_exp_f32")
+    BOTH(11, "1 v_exp_legacy_f32")
+    BOTH(16, "2 v_exp_legacy_f32")
+    BOTH(12, "1 v_exp_f16")
+    BOTH(17, "2 v_exp_f16")
+    BOTH(13, "scalar gap on v_exp_legacy_f32")
+    BOTH(14, "16-bit gap: v_fma_mixlo_f16 + v_exp_f16 + v_fma_mix_f32")
     return 0;
 }
