@@ -63,6 +63,13 @@ CASES = [  # B, Hq, Hkv, Sq, Sk, D
     (1, 10, 10, 700, 700, 128),    # more heads than XCDs: persistent workgroups walk several units
     (1, 2, 1, 300, 300, 256),      # head_dim 256 (its own kernel, whatever prefill_impl says), GQA, ragged
     (2, 3, 3, 129, 400, 256),      # Sq < Sk
+    # more q-tiles than persistent workgroups (36 units per XCD list against 32 slots) and very few keys: the 4-wave kernel
+    # chains q-tiles of one, two, three and five tiles -- the seam half-step, the Q fetch in the gaps and its fallback at the
+    # top of a q-tile, the Q request at the top of q-tiles of one or two tiles; causal: most q-tiles see no key at all
+    (2, 16, 16, 2304, 64, 128),
+    (2, 16, 16, 2304, 128, 128),
+    (2, 16, 4, 2304, 192, 128),
+    (2, 16, 16, 2304, 320, 128),
 ]
 
 
