@@ -149,3 +149,16 @@ def test_fuzz_decode_grouped(sfa, seed):
         sfa.debug_set("decode_gqa_mfma", -1)
     np.testing.assert_allclose(o.float().cpu().numpy(), ref["o"], atol=TOL[dtype], rtol=TOL[dtype],
                                err_msg=f"B={B} H={H} Hkv={Hkv} D={D} M={M} rot={rot} splits={splits} {layout} lens={lens} force={force}")
+
+
+def test_fuzz_w4_chained_qtiles_against_the_128_row_kernel():
+    """tools/w4_fuzz.py: 96 seeded shapes with more q-tiles than persistent workgroups (every seam path of the 4-wave kernel)
+    against the 128-row kernel, output and log-sum-exp."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "w4_fuzz.py"), "96"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 mismatch(es) in 96 cases" in r.stdout
