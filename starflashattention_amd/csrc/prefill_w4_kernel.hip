@@ -6,9 +6,9 @@
 // Structure (unchanged from round 2, prefill_w4r2_kernel.hip -- kept in the A/B library):
 //   * workgroup = 4 waves = one 256-row q-tile; a wave owns 64 query rows = two 32-row query blocks, so every
 //     K / V fragment read from LDS feeds TWO MFMAs; one wave per SIMD with the whole 512-entry register file.
-//   * O^T (128 registers) and the Q^T fragments (64) live in the ACCUMULATOR half of the register file: the
-//     MFMAs are inline asm with "a"-constrained operands.  Scores, P, the K / V fragments and the softmax state
-//     stay in the 256 arch VGPRs.
+//   * O^T (128 registers) and the Q^T fragments (64) live in the ACCUMULATOR half of the register file, by NAME
+//     (a[0:127], a[128:191]: "the asm-owned half of the register file" below).  Scores, P, the K / V fragments, the
+//     masks and the softmax state stay in the 256 arch VGPRs.
 //   * S^T = K . Q^T and O^T += V^T . P^T with v_mfma_f32_32x32x16: the query sits on the lane in both
 //     accumulators, the exponentiated S^T registers ARE the B operand of the PV product, V^T comes out of
 //     the row-major tile through ds_read_b64_tr_b16.
@@ -32,7 +32,11 @@
 //     rows in the steps it would otherwise idle through; only the wave that owns the diagonal's end has an
 //     exposed epilogue;
 //   * the cursors advance by additions (one division per launch), and the Q rows of the next q-tile are requested
-//     two to three steps ahead behind a COUNTED vmcnt.
+//     two to three steps ahead behind a COUNTED vmcnt, and fetched into the accumulator file in the MFMA gaps of the
+//     wave's last half-step that still scores (or in an idle step), not at the top of the q-tile;
+//   * masks are the C operand of a block's first QK^T MFMA (the inner tiles' half-steps carry no mask code);
+//   * kernel arguments are precomputed on the host (W4Args) and re-read in bursts where a q-tile begins or ends.
+// Measurements, and what was tried and not kept: DESIGN.md 5.2 "Round 3", profiles/r03_power_clock.txt.
 //
 // Hazards hipcc does not see inside the asm MFMAs (cdna_hip_programming.md section 5.7): (1) an MFMA's result
 // read or overwritten by the VALU needs the MFMA to have drained -- in the full half-step at least two other
