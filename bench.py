@@ -444,6 +444,15 @@ def main():
                 rec["decode_roofline"] = bench_decode(torch, sfa, min(50, max(3, args.steps // 2)), 3)
             except Exception as e:                      # the headline number must still print
                 rec["decode_roofline"] = {"error": repr(e)[:200]}
+            # the headline workload once more, now that the device has been busy for seconds: with few --steps / --warmup the
+            # timed region above sits in the first ~50 ms after start-up, where launches run up to 6 % slower (never `value`)
+            try:
+                ms, tf, name = time_prefill(torch, sfa, B, H, S, D, causal, 100, warmup=20, seed=1234)
+                rec["headline_warm"] = {"workload": "the headline workload again at the end of this run, 100 steps after 20 warm-ups",
+                                        "kernel": name, "ms_per_step": round(ms, 4), "tflops": round(tf, 2),
+                                        "frac_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+            except Exception as e:
+                rec["headline_warm"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(rec), flush=True)
