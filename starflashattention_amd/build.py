@@ -25,7 +25,9 @@ ARCH = "gfx950"
 
 EXTRA_FLAGS = {}      # per-source extra hipcc flags
 
-KERNEL_SOURCES = ["decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_w4_kernel.hip", "prefill_w4d_kernel.hip", "prefill_d256_kernel.hip",
+# (the longest compiles first: the pool below takes the sources in this order)
+KERNEL_SOURCES = ["prefill_w4_kernel.hip", "prefill_w4_kernel_p1.hip", "prefill_w4_kernel_p2.hip", "prefill_w4_kernel_p3.hip",
+                  "prefill_w4d_kernel.hip", "decode_kernel.hip", "decode_gqa_kernel.hip", "decode_gqa_mfma_kernel.hip", "prefill_d256_kernel.hip",
                   "prefill_kernel.hip", "prefill_kernel_bm128.hip", "prefill_dispatch.hip",
                   "aux_kernels.hip", "c_api.hip", "cxx_surface.hip"]
 # Earlier kernel generations kept for A/B runs (tools/prefill_ab.py, pytest -m variants).  They are never an
@@ -60,6 +62,7 @@ def _stamp(paths, extra=""):
 
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(CSRC, "prefill_w4_kernel.hip")]        # included by prefill_w4_kernel_p1..3.hip
     hs += [os.path.join(ROOT, "include", "star_flash_attn.h")]
     hs += [os.path.join(ROOT, "src", f) for f in ("params.h", "traits.h", "flash_attn.h")]
     return [h for h in hs if os.path.exists(h)]
@@ -101,7 +104,7 @@ def build_lib(force=False, verbose=False, extra_flags=(), variants=False):
             f.write(ostamp)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 4, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
     with open(stamp_file, "w") as f:

@@ -56,6 +56,11 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
                       int force = 0);
 // whether one head's Q / K / V rows fit the 32-bit buffer descriptors of the 4-wave kernel (else: the 8-wave kernel)
 bool prefill_w4_serves(const PrefillKernelParams &p, int head_dim);
+// the flavours of the 4-wave kernel that live in translation units of their own (prefill_w4_kernel_p1..3.hip; bf16 exact
+// scale is in prefill_w4_kernel.hip itself): called by launch_prefill_w4 only
+int launch_prefill_w4_fp16_exact(const PrefillKernelParams &p, bool causal, hipStream_t stream);
+int launch_prefill_w4_fp16_prescaled(const PrefillKernelParams &p, bool causal, hipStream_t stream);
+int launch_prefill_w4_bf16_prescaled(const PrefillKernelParams &p, bool causal, hipStream_t stream);
 // round 2's generation of the 4-wave kernel (q-tiles scored and finished outside the pipeline) and its stamping /
 // ablation builds: the A/B library only (prefill_w4r2_kernel.hip)
 int launch_prefill_w4r2(const PrefillKernelParams &p, int dtype, int head_dim, bool causal, hipStream_t stream,

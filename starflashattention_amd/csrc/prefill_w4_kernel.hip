@@ -1239,6 +1239,20 @@ int launch_w4_t(const PrefillKernelParams &p, bool causal, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef SFA_W4_PART
+// One flavour per translation unit (prefill_w4_kernel_p1..3.hip include this file with SFA_W4_PART set): the four flavours
+// compile side by side instead of one after the other (each takes about two minutes).
+#if SFA_W4_PART == 1
+int launch_prefill_w4_fp16_exact(const PrefillKernelParams &p, bool causal, hipStream_t stream) { return launch_w4_t<Fp16, 128, 2>(p, causal, stream); }
+#elif SFA_W4_PART == 2
+int launch_prefill_w4_fp16_prescaled(const PrefillKernelParams &p, bool causal, hipStream_t stream) { return launch_w4_t<Fp16, 128, 6>(p, causal, stream); }
+#elif SFA_W4_PART == 3
+int launch_prefill_w4_bf16_prescaled(const PrefillKernelParams &p, bool causal, hipStream_t stream) { return launch_w4_t<Bf16, 128, 6>(p, causal, stream); }
+#else
+#error "SFA_W4_PART is 1, 2 or 3"
+#endif
+#else   // the main translation unit: bf16 exact (the headline kernel), the diagnostics of the A/B library, the entry point
+
 // The K / V / Q rows of one head are addressed through 32-bit buffer descriptors: a head whose rows span 2 GiB or
 // more, or a row stride of 16 MiB or more, is served by the 8-wave kernel instead (prefill_dispatch.hip).
 bool prefill_w4_serves(const PrefillKernelParams &p, int head_dim) {
@@ -1267,9 +1281,10 @@ int launch_prefill_w4(const PrefillKernelParams &p, int dtype, int head_dim, boo
     return launch_w4_t<Bf16, 128, 2>(p, causal, stream);
 #else
     if (dtype == SFA_DTYPE_FP16)
-        return prescaled ? launch_w4_t<Fp16, 128, 6>(p, causal, stream) : launch_w4_t<Fp16, 128, 2>(p, causal, stream);
-    return prescaled ? launch_w4_t<Bf16, 128, 6>(p, causal, stream) : launch_w4_t<Bf16, 128, 2>(p, causal, stream);
+        return prescaled ? launch_prefill_w4_fp16_prescaled(p, causal, stream) : launch_prefill_w4_fp16_exact(p, causal, stream);
+    return prescaled ? launch_prefill_w4_bf16_prescaled(p, causal, stream) : launch_w4_t<Bf16, 128, 2>(p, causal, stream);
 #endif
 }
+#endif  // SFA_W4_PART
 
 }  // namespace sfa
